@@ -1,0 +1,2 @@
+"""andvaranaut_amd: MI355X-native GP log-marginal-likelihood backend behind andvaranaut's GPMCMC surface."""
+from .backend import MiGP, pack_theta, parse_kernel  # noqa: F401

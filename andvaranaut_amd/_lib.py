@@ -1,0 +1,90 @@
+"""ctypes binding of libmi_gp.so (include/mi_gp.h).  There is no CPU fallback: if the HIP library
+is missing the import of the product path fails loudly."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmi_gp.so")
+
+MAX_KERN = 4
+KERNEL_IDS = {"RBF": 0, "Matern52": 1, "Matern32": 2, "Exponential": 3, "RatQuad": 4}
+OP_IDS = {"+": 0, "*": 1}
+
+
+class MiGpConfig(ctypes.Structure):
+    _fields_ = [
+        ("n", ctypes.c_int),
+        ("d", ctypes.c_int),
+        ("nkern", ctypes.c_int),
+        ("kernel_ids", ctypes.c_int * MAX_KERN),
+        ("ops", ctypes.c_int * MAX_KERN),
+        ("device", ctypes.c_int),
+        ("panel_tiles", ctypes.c_int),
+    ]
+
+
+class MiGpBuffers(ctypes.Structure):
+    _fields_ = [
+        ("X_dev", ctypes.c_void_p),
+        ("y_dev", ctypes.c_void_p),
+        ("K_dev", ctypes.c_void_p),
+        ("lda", ctypes.c_long),
+        ("Z_dev", ctypes.c_void_p),
+        ("W_dev", ctypes.c_void_p),
+    ]
+
+
+_lib = None
+
+
+def load():
+    """Load libmi_gp.so and declare every entry point of include/mi_gp.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C andvaranaut_amd/csrc` (there is no CPU fallback for the GP hot path)"
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, ci, cl, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_double
+    dp = ctypes.POINTER(ctypes.c_double)
+    lib.mi_gp_last_global_error.restype = ctypes.c_char_p
+    lib.mi_gp_last_error.restype = ctypes.c_char_p
+    lib.mi_gp_last_error.argtypes = [vp]
+    lib.mi_gp_create.argtypes = [ctypes.POINTER(MiGpConfig), ctypes.POINTER(vp)]
+    lib.mi_gp_destroy.argtypes = [vp]
+    lib.mi_gp_padded_n.argtypes = [vp]
+    lib.mi_gp_padded_n.restype = cl
+    lib.mi_gp_num_theta.argtypes = [vp]
+    lib.mi_gp_stream.argtypes = [vp]
+    lib.mi_gp_stream.restype = vp
+    lib.mi_gp_set_data.argtypes = [vp, ctypes.POINTER(MiGpBuffers)]
+    lib.mi_gp_lml.argtypes = [vp, dp, dp]
+    lib.mi_gp_lml_parts.argtypes = [vp, dp, dp]
+    lib.mi_gp_set_profiling.argtypes = [vp, ci]
+    lib.mi_gp_timers.argtypes = [vp, dp, ci]
+    lib.mi_gp_gemm_f64.argtypes = [ci, ci, ci, ci, ci, cd, vp, cl, vp, cl, cd, vp, cl, ci, ci, ci, cl, cl, cl, vp]
+    for name in EXPORTS:
+        getattr(lib, name)  # raises AttributeError if a declared symbol is missing
+    _lib = lib
+    return lib
+
+
+# every symbol include/mi_gp.h declares (checked by tests/test_abi.py against the header text)
+EXPORTS = [
+    "mi_gp_last_global_error",
+    "mi_gp_last_error",
+    "mi_gp_create",
+    "mi_gp_destroy",
+    "mi_gp_padded_n",
+    "mi_gp_num_theta",
+    "mi_gp_stream",
+    "mi_gp_set_data",
+    "mi_gp_lml",
+    "mi_gp_lml_parts",
+    "mi_gp_set_profiling",
+    "mi_gp_timers",
+    "mi_gp_gemm_f64",
+]

@@ -1,0 +1,125 @@
+"""Device-side GP engine: owns the PyTorch-ROCm buffers and drives libmi_gp.so through ctypes.
+
+Mirrors what the reference keeps inside its PyMC model object ``m``/``gp`` (gpmcmc.py:178,401):
+the training inputs, the kernel structure, and a way to evaluate logp / dlogp / the conditional."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def parse_kernel(kernel):
+    """Kernel-string grammar of GPMCMC.change_model (gpmcmc.py:497-505): names joined by + or *."""
+    import re
+
+    kerns = re.split(r"[+*]", kernel)
+    ops = [ch for ch in kernel if ch in "+*"]
+    for k in kerns:
+        if k not in _lib.KERNEL_IDS:
+            raise Exception(f"Error: kernel string must contain only {list(_lib.KERNEL_IDS)}")
+    if len(kerns) > _lib.MAX_KERN:
+        raise Exception(f"Error: at most {_lib.MAX_KERN} kernel components are supported")
+    return kerns, ops
+
+
+def pack_theta(ls, kv, gv, jitter, alpha=None):
+    """C-ABI theta layout: [ls(nkern*d), kv(nkern), alpha(nkern), gv, jitter]."""
+    ls = np.atleast_2d(np.asarray(ls, dtype=np.float64))
+    kv = np.atleast_1d(np.asarray(kv, dtype=np.float64))
+    alpha = np.ones_like(kv) if alpha is None else np.atleast_1d(np.asarray(alpha, dtype=np.float64))
+    return np.concatenate([ls.ravel(), kv, alpha, [float(gv), float(jitter)]])
+
+
+class MiGP:
+    """One GP data set + kernel structure bound to one MI355X and one HIP stream."""
+
+    def __init__(self, X, y, kernel="RBF", device=0, panel_tiles=0, need_grad=True):
+        if not torch.cuda.is_available():
+            raise RuntimeError("MiGP needs a ROCm GPU: the GP hot path has no CPU implementation")
+        self.lib = _lib.load()
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        y = np.ascontiguousarray(np.asarray(y, dtype=np.float64).reshape(-1))
+        if X.ndim != 2 or X.shape[0] != y.shape[0]:
+            raise ValueError("X must be (n,d) and y (n,)")
+        self.n, self.d = X.shape
+        self.kerns, self.ops = parse_kernel(kernel)
+        self.nkern = len(self.kerns)
+        self.device = int(device)
+        self.dev = torch.device("cuda", self.device)
+        cfg = _lib.MiGpConfig()
+        cfg.n, cfg.d, cfg.nkern = self.n, self.d, self.nkern
+        for i, k in enumerate(self.kerns):
+            cfg.kernel_ids[i] = _lib.KERNEL_IDS[k]
+        for i, o in enumerate(self.ops):
+            cfg.ops[i] = _lib.OP_IDS[o]
+        cfg.device = self.device
+        cfg.panel_tiles = int(panel_tiles)
+        h = ctypes.c_void_p()
+        r = self.lib.mi_gp_create(ctypes.byref(cfg), ctypes.byref(h))
+        if r != 0:
+            raise RuntimeError(f"mi_gp_create failed ({r}): {self.lib.mi_gp_last_global_error()}")
+        self.h = h
+        self.np_ = int(self.lib.mi_gp_padded_n(h))
+        self.ntheta = int(self.lib.mi_gp_num_theta(h))
+        # leading dimension: padded n plus 16 doubles so that column panels are not power-of-two strided
+        self.lda = self.np_ + 16
+        with torch.cuda.device(self.dev):
+            self.X_t = torch.from_numpy(X).to(self.dev)
+            self.y_t = torch.from_numpy(y).to(self.dev)
+            self.K_t = torch.empty((self.np_ + 128, self.lda), dtype=torch.float64, device=self.dev)
+            self.Z_t = self.W_t = None
+            if need_grad:
+                self.Z_t = torch.zeros((self.np_, self.lda), dtype=torch.float64, device=self.dev)
+                self.W_t = torch.zeros((self.np_, self.lda), dtype=torch.float64, device=self.dev)
+            torch.cuda.synchronize(self.dev)
+        b = _lib.MiGpBuffers()
+        b.X_dev, b.y_dev, b.K_dev = self.X_t.data_ptr(), self.y_t.data_ptr(), self.K_t.data_ptr()
+        b.lda = self.lda
+        b.Z_dev = self.Z_t.data_ptr() if need_grad else None
+        b.W_dev = self.W_t.data_ptr() if need_grad else None
+        self._check(self.lib.mi_gp_set_data(h, ctypes.byref(b)), "mi_gp_set_data")
+
+    def _check(self, r, what):
+        if r < 0:
+            raise RuntimeError(f"{what} failed ({r}): {self.lib.mi_gp_last_error(self.h).decode()}")
+        return r
+
+    def _theta(self, theta):
+        theta = np.ascontiguousarray(theta, dtype=np.float64)
+        if theta.shape != (self.ntheta,):
+            raise ValueError(f"theta must have {self.ntheta} entries")
+        return theta, theta.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+    def lml(self, theta):
+        """LML at natural-scale theta; -inf if K is not positive definite (info > 0)."""
+        theta, tp = self._theta(theta)
+        out = ctypes.c_double()
+        self.info = self._check(self.lib.mi_gp_lml(self.h, tp, ctypes.byref(out)), "mi_gp_lml")
+        return out.value
+
+    def lml_parts(self):
+        a, b = ctypes.c_double(), ctypes.c_double()
+        self.lib.mi_gp_lml_parts(self.h, ctypes.byref(a), ctypes.byref(b))
+        return a.value, b.value
+
+    def set_profiling(self, level):
+        self.lib.mi_gp_set_profiling(self.h, int(level))
+
+    def timers(self):
+        out = (ctypes.c_double * 7)()
+        self.lib.mi_gp_timers(self.h, out, 7)
+        keys = ["assemble_ms", "cholesky_ms", "reduce_ms", "total_ms", "gemm_ms", "gemm_flops", "gemm_launches"]
+        return dict(zip(keys, list(out)))
+
+    def close(self):
+        if getattr(self, "h", None) is not None:
+            self.lib.mi_gp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

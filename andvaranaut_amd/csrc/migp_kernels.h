@@ -23,4 +23,30 @@ struct GemmParams {
 hipError_t launch_gemm_f64(const GemmParams& p, int opA_kmajor, int opB_kmajor, int batch, hipStream_t stream);
 hipError_t gemm_f64_enable_lds();
 
+// ---------------------------------------------------------------- leaf_f64.hip
+hipError_t leaf_enable_lds();
+// in-place lower Cholesky of one 128x128 diagonal block; dinv receives the inverses of its eight
+// 16x16 diagonal sub-blocks ([8][16][16]); *info gets atomicMin(col0 + j + 1) on a bad pivot.
+hipError_t launch_potrf_leaf128(double* Ablk, long lda, double* dinv, int col0, int* info, hipStream_t stream);
+// X * L^T = B in place on the m x 128 panel B (m multiple of 64).
+hipError_t launch_trsm_strip128(const double* Lblk, long lda, const double* dinv, double* B, long ldb, int m,
+                                hipStream_t stream);
+
+// ---------------------------------------------------------------- assemble.hip
+enum { KID_RBF = 0, KID_MATERN52 = 1, KID_MATERN32 = 2, KID_EXPONENTIAL = 3, KID_RATQUAD = 4 };
+constexpr int MAX_KERN = 4;
+struct KernSpec {
+  int nkern;
+  int d;
+  int kid[MAX_KERN];
+  int op[MAX_KERN];  // op[i] joins component i and i+1: 0 '+', 1 '*'
+};
+// sym=1: lower 64x64 tiles of K(X1,X1) + noise on the diagonal, identity in the padding;
+// sym=0: full K(X1,X2), zeros in the padding.  noise_form: 0 marginal, 1 conditional, 2 explicit.
+hipError_t launch_assemble(const KernSpec& spec, const double* theta, const double* X1, int n1, const double* X2,
+                           int n2, double* K, long ldk, int rows_pad, int cols_pad, int sym, int noise_form,
+                           hipStream_t stream);
+hipError_t launch_set_yrows(double* K, long ldk, int row0, int cols_pad, const double* y, int n, hipStream_t stream);
+hipError_t launch_lml_reduce(const double* L, long ld, const double* beta, int n, double* out, hipStream_t stream);
+
 }  // namespace migp

@@ -2,11 +2,22 @@
  *
  * The reference (andrew-angus/andvaranaut) has no FFI for this path: the seam is the PyMC model
  * built in GPMCMC.__fit (gpmcmc.py:189-323) and consumed by pm.find_MAP / pm.sample / gp.predict
- * (gpmcmc.py:345,351,593).  Each entry point below names the reference call site it replaces.
- * All pointers marked _dev are device (HBM) addresses, e.g. torch.Tensor.data_ptr(); the library
- * borrows them and never frees them.  Every function returns int:
- *   0  ok;  >0  LAPACK-style info (1-based index of the first non-positive pivot);
- *   <0 bad argument (-1) or HIP/RCCL failure (-2); text via mi_gp_last_global_error().
+ * (gpmcmc.py:345,351,593).  In PyMC terms that seam is one value-and-gradient callable
+ * theta -> (logp, dlogp) and one conditional (theta, X*) -> (mu*, var*); the entry points below
+ * are exactly those two, plus the block-level operations they are built from.  Each entry point
+ * names the reference call site it replaces.
+ *
+ * Conventions
+ *  - all arrays are float64, row-major; pointers named *_dev are device (HBM) addresses, e.g.
+ *    torch.Tensor.data_ptr(); the library borrows them and never frees them;
+ *  - theta is a HOST array in natural (untransformed) scale:
+ *        [ ls(nkern*d) | kv(nkern) | alpha(nkern, RatQuad only) | gv | jitter ]
+ *    host Python applies priors, log/interval transforms and their Jacobians (gpmcmc.py:193-208);
+ *  - every function returns int: 0 ok; >0 LAPACK-style info = 1-based index of the first
+ *    non-positive pivot (the LML is then -inf, as PyMC's "posdef" check gives);
+ *    <0 bad argument (-1) or HIP/RCCL failure (-2); text via mi_gp_last_error().  Never aborts.
+ *  - a handle is bound to one device and one HIP stream and is NOT thread-safe; calls return after
+ *    the stream has been synchronised (scalar outputs are valid on return).
  */
 #ifndef MI_GP_H
 #define MI_GP_H
@@ -14,7 +25,55 @@
 extern "C" {
 #endif
 
+enum { MI_GP_RBF = 0, MI_GP_MATERN52 = 1, MI_GP_MATERN32 = 2, MI_GP_EXPONENTIAL = 3, MI_GP_RATQUAD = 4 };
+enum { MI_GP_OP_ADD = 0, MI_GP_OP_MUL = 1 };
+#define MI_GP_MAX_KERN 4
+
+typedef struct mi_gp_handle mi_gp_handle;
+
+/* kernel string of GPMCMC.change_model (gpmcmc.py:497-515) already split into ids and ops */
+typedef struct mi_gp_config {
+  int n;                          /* training points */
+  int d;                          /* input dimensions (nx) */
+  int nkern;                      /* kernel components, <= MI_GP_MAX_KERN */
+  int kernel_ids[MI_GP_MAX_KERN]; /* MI_GP_RBF ... */
+  int ops[MI_GP_MAX_KERN];        /* ops[i] joins component i and i+1, applied left to right */
+  int device;                     /* HIP device ordinal */
+  int panel_tiles;                /* Cholesky super-panel width in 128-column tiles; 0 = default */
+} mi_gp_config;
+
+/* device buffers, allocated by the caller (PyTorch tensors in the Python host) */
+typedef struct mi_gp_buffers {
+  const double* X_dev; /* n x d   converted inputs  (xin of gpmcmc.py:235-237) */
+  const double* y_dev; /* n       converted outputs (yin of gpmcmc.py:279)     */
+  double* K_dev;       /* (np+128) x lda, np = mi_gp_padded_n(): covariance, overwritten by its
+                          lower Cholesky factor; the extra 128 rows carry y^T -> beta^T = (L^-1 y)^T */
+  long lda;            /* leading dimension of K/Z/W in elements: even, >= np */
+  double* Z_dev;       /* np x lda  L^-1   (needed by mi_gp_lml_grad only; may be NULL otherwise) */
+  double* W_dev;       /* np x lda  K^-1   (needed by mi_gp_lml_grad only; may be NULL otherwise) */
+} mi_gp_buffers;
+
 const char* mi_gp_last_global_error(void);
+const char* mi_gp_last_error(mi_gp_handle* h);
+
+int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out);
+int mi_gp_destroy(mi_gp_handle* h);
+long mi_gp_padded_n(const mi_gp_handle* h);   /* n rounded up to a multiple of 128 */
+int mi_gp_num_theta(const mi_gp_handle* h);   /* nkern*d + 2*nkern + 2 */
+void* mi_gp_stream(const mi_gp_handle* h);    /* the handle's hipStream_t */
+int mi_gp_set_data(mi_gp_handle* h, const mi_gp_buffers* buffers);
+
+/* LML(theta) = -1/2 |L^-1 y|^2 - sum log L_ii - n/2 log 2pi with L = chol(K(theta) + gv I + jitter I).
+ * Replaces the logp evaluation of gp.marginal_likelihood (gpmcmc.py:321-323; explicit form :311-318). */
+int mi_gp_lml(mi_gp_handle* h, const double* theta_host, double* lml_out);
+/* sum log L_ii and |L^-1 y|^2 of the last factorisation */
+int mi_gp_lml_parts(mi_gp_handle* h, double* logdet_out, double* quad_out);
+
+/* profiling: level 0 none, 1 per-phase HIP events, 2 additionally per-GEMM-launch HIP events */
+int mi_gp_set_profiling(mi_gp_handle* h, int level);
+/* out[0..6] = assemble_ms, cholesky_ms, reduce_ms, total_ms, gemm_ms (sum over launches),
+ *             gemm_flops (algorithmic), number of gemm launches -- of the last evaluation */
+int mi_gp_timers(mi_gp_handle* h, double* out, int n);
 
 /* ---- block-level operations (also used by the multi-GPU driver and the parity tests) ---- */
 

@@ -163,8 +163,12 @@ static hipError_t syrk_trapezoid(mi_gp_handle* h, double* A, long lda, int ntr, 
   p.kmode = 0;
   p.alpha = -1.0;
   p.beta = 1.0;
-  const double ntiles = (double)nc * (nc + 1) / 2 + (double)(p.mt - nc) * nc;
-  return prof_gemm(h, p, 0, 0, 1, ntiles * 128.0 * 128.0 * p.k * 2.0);
+  // algorithmic flops (nb*m^2 for the lower-triangle SYRK, 2*nb*rows*cols for the block
+  // below it, one y^T row for the folded-in forward solve); the MFMA work issued is slightly larger
+  // (full diagonal tiles, a 128-row tile for the y row).
+  const double c = nc * 128.0, rows_real = (p.mt - 1) * 128.0;
+  const double flops = (double)p.k * (c * (c + 1.0) + 2.0 * (rows_real - c) * c + 2.0 * c);
+  return prof_gemm(h, p, 0, 0, 1, flops);
 }
 
 // factor tile columns [c0, c0+w) of the (ntr x ntc)-tile trapezoid, recursively halving w

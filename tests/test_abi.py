@@ -1,0 +1,45 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol include/mi_gp.h declares."""
+import os
+import re
+
+from conftest import ROOT
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "mi_gp.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mi_gp_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from andvaranaut_amd import _lib
+
+    lib = _lib.load()
+    names = _declared()
+    assert len(names) >= 10
+    for n in names:
+        assert hasattr(lib, n), f"libmi_gp.so does not export {n}"
+    assert sorted(_lib.EXPORTS) == names, "andvaranaut_amd/_lib.py:EXPORTS is out of sync with include/mi_gp.h"
+
+
+def test_bad_arguments_are_reported_not_crashed():
+    import ctypes
+
+    from andvaranaut_amd import _lib
+
+    lib = _lib.load()
+    # no GPU needed: argument validation happens before any HIP call
+    assert lib.mi_gp_gemm_f64(0, 1, 100, 128, 16, 1.0, None, 16, None, 16, 0.0, None, 128, 0, 0, 1, 0, 0, 0, None) == -1
+    assert b"multiples" in lib.mi_gp_last_global_error()
+    cfg = _lib.MiGpConfig()
+    cfg.n, cfg.d, cfg.nkern = 0, 1, 1
+    h = ctypes.c_void_p()
+    assert lib.mi_gp_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
+
+
+def test_product_package_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "andvaranaut_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("# oracle", ""), f"{f} mentions the oracle"

@@ -24,8 +24,8 @@ static int ensure_init() {
 extern "C" int mi_gp_gemm_f64(int transa, int transb, int m, int n, int k, double alpha, const double* A, long lda,
                               const double* B, long ldb, double beta, double* C, long ldc, int tri, int kmode,
                               int batch, long strideA, long strideB, long strideC, void* stream) {
-  if (m % 128 || n % 128 || k % 16 || m <= 0 || n <= 0 || k < 0 || (lda & 1) || (ldb & 1)) {
-    snprintf(g_err, sizeof(g_err), "mi_gp_gemm_f64: m,n must be multiples of 128, k of 16, lda/ldb even");
+  if (m % 128 || n % 128 || k % 32 || m <= 0 || n <= 0 || k < 0 || (lda & 1) || (ldb & 1)) {
+    snprintf(g_err, sizeof(g_err), "mi_gp_gemm_f64: m,n must be multiples of 128, k of 32, lda/ldb even");
     return -1;
   }
   if (int r = ensure_init()) return r;

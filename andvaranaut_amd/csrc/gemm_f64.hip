@@ -1,22 +1,20 @@
-// fp64 tiled GEMM / SYRK for gfx950 on v_mfma_f64_4x4x4_4b_f64.
+// fp64 tiled GEMM / SYRK for gfx950 on v_mfma_f64_16x16x4_f64 with VGPR accumulators.
 //
-// Why the 4x4x4 form: measured on MI355X (profiles/r01_probe_*.txt) v_mfma_f64_16x16x4_f64
-// issues every ~139 cycles (35.8 TFLOP/s chip-wide) while v_mfma_f64_4x4x4_4b_f64 issues every
-// ~17 cycles (74.8 TFLOP/s, the 78.6 TFLOP/s fp64 peak).  The 4-block instruction only forms the
-// four DIAGONAL 4x4 blocks of a 16x16 outer product, so each 16x16 output tile is built from four
-// MFMAs whose B operand has its 4-column blocks rotated by s = 0..3 (the rotation is free: it is
-// just a different LDS read address per lane).  Lane maps (decoded by one-hot probing,
-// profiles/r01_probe_mfma_f64_4x4x4_lanemap.txt):
-//   A operand lane p : A_blk[i][k]  with k = p>>4, blk = (p>>2)&3, i = p&3
-//   B operand lane p : B_blk[k][j]  with k = p>>4, blk = (p>>2)&3, j = p&3
-//   D result  lane l : D_blk[i][j]  with i = l>>4, blk = (l>>2)&3, j = l&3
-//   blgp bit0 negates A, bit1 negates B; cbsz/abid have no effect on this opcode.
+// Measured on MI355X (profiles/r01_probe_*.txt): v_mfma_f64_16x16x4_f64 issues every 64.0 cycles
+// (77.0 TFLOP/s chip-wide, 98 % of the 78.6 TFLOP/s fp64 peak) when its C/D operand lives in VGPRs,
+// but every 130 cycles (38 TFLOP/s) when C/D is in AGPRs -- so this library is compiled with
+// -mllvm -amdgpu-mfma-vgpr-form.  (v_mfma_f64_4x4x4_4b_f64 reaches 75.8 TFLOP/s from either file;
+// its lane map is in profiles/r01_probe_mfma_f64_4x4x4_lanemap.txt.)
+// Lane maps of the 16x16x4 form (one f64 of A and of B per lane, 4 f64 of C/D per lane):
+//   A[i = l&15][k = l>>4]   B[k = l>>4][j = l&15]   D[row = (l>>4) + 4r][col = l&15], r = 0..3
 //
-// Work decomposition: 128x128 output tile per 256-thread workgroup (4 waves as 2x2, 64x64 per
-// wave = 4x4 tiles of 16x16 = 64 accumulator doubles per lane), K consumed in chunks of 16 through
-// a double-buffered LDS image stored k-major ([k][x], leading dimension 144 doubles so both
-// halves of a ds_read_b64 wave access hit disjoint banks).  Two workgroups per CU so one
-// workgroup's C read-modify-write epilogue overlaps the other's MFMA loop.
+// Work decomposition: 128x128 output tile per 512-thread workgroup (8 waves as 2x4, 64x32 per
+// wave = 4x2 MFMA tiles = 32 accumulator doubles per lane), K consumed in chunks of 32 through a
+// double-buffered LDS image stored k-major ([k][x], leading dimension 144 doubles so both halves
+// of a ds_read_b64 wave access hit disjoint banks).  The next chunk travels global -> registers
+// during the first half of the current chunk's MFMAs and registers -> LDS in its middle; MFMA
+// operand fragments are double-buffered in registers one k4-step ahead; the C tile is fetched at the
+// start of the last chunk so the read-modify-write epilogue does not expose HBM latency.
 //
 // This kernel serves: K3 Cholesky trailing / panel updates (NT, lower),
 // K7 triangular inverse levels (NN with triangular k-ranges) and L^-T L^-1 (TN), K8 predict
@@ -26,42 +24,52 @@
 namespace migp {
 
 typedef double double2_t __attribute__((ext_vector_type(2)));
+typedef double double4_t __attribute__((ext_vector_type(4)));
 
 constexpr int TILE = 128;
-constexpr int BK = 16;
+constexpr int BK = 32;
 constexpr int LDS_LD = 144;
 constexpr int OPER_ELEMS = BK * LDS_LD;  // one operand chunk in LDS
+constexpr int NTHREADS = 512;
+constexpr int NQ = TILE * BK / 2 / NTHREADS;  // 16-byte pieces per thread per operand chunk
+constexpr int KC = BK / 2;                    // 16-byte pieces per x-major row
 
-// Stage one 128 x 16 operand chunk from global memory into registers.
-// XMAJOR: memory is [x][k] (x = row of A or column of B), KMAJOR: memory is [k][x].
+// Staging of one 128 x BK operand chunk (512 threads, NQ x 16 B each).  XMAJOR: memory is [x][k]
+// (x = row of A or column of B), KMAJOR: memory is [k][x].  Per-thread byte offsets are 32-bit and
+// loop-invariant; the chunk advance is a uniform (scalar) pointer increment.
+// Thread t owns piece (q, t): XMAJOR  x = 32q + (t>>8)*16 + (t&15), k-pair = (t>>4)&15;
+//                              KMAJOR  k = 8q + (t>>6),               x-pair = t&63.
+// so the q-dependence is a uniform stride in global memory and an immediate offset in LDS.
 template <bool KMAJOR>
-__device__ __forceinline__ void chunk_load(const double* __restrict__ base, long ld, int x0, int k0, int tid,
-                                           double2_t (&r)[4]) {
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int p = tid + 256 * q;
-    if (KMAJOR) {
-      const int k = p >> 6, xc = p & 63;
-      r[q] = *reinterpret_cast<const double2_t*>(base + (long)(k0 + k) * ld + x0 + 2 * xc);
-    } else {
-      const int xl = p & 15, kc = (p >> 4) & 7, xh = p >> 7;
-      r[q] = *reinterpret_cast<const double2_t*>(base + (long)(x0 + xh * 16 + xl) * ld + k0 + 2 * kc);
-    }
+__device__ __forceinline__ void chunk_offsets(long ld, int tid, unsigned& goff, unsigned& loff, long& gstride) {
+  if (KMAJOR) {
+    const int k = tid >> 6, xc = tid & 63;
+    goff = (unsigned)((k * ld + 2 * xc) * 8);
+    loff = (unsigned)((k * LDS_LD + 2 * xc) * 8);
+    gstride = 8 * ld * 8;
+  } else {
+    const int xl = tid & 15, kc = (tid >> 4) & 15, xh = tid >> 8;
+    goff = (unsigned)(((xh * 16 + xl) * ld + 2 * kc) * 8);
+    loff = (unsigned)(((2 * kc) * LDS_LD + xh * 16 + xl) * 8);
+    gstride = 32 * ld * 8;
   }
 }
 
-template <bool KMAJOR>
-__device__ __forceinline__ void chunk_store(double* __restrict__ lds, int tid, const double2_t (&r)[4]) {
+__device__ __forceinline__ void chunk_load(const char* __restrict__ base, unsigned goff, long gstride,
+                                           double2_t (&r)[NQ]) {
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int p = tid + 256 * q;
+  for (int q = 0; q < NQ; ++q) r[q] = *reinterpret_cast<const double2_t*>(base + q * gstride + goff);
+}
+
+template <bool KMAJOR>
+__device__ __forceinline__ void chunk_store(char* __restrict__ lds, unsigned loff, const double2_t (&r)[NQ]) {
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
     if (KMAJOR) {
-      const int k = p >> 6, xc = p & 63;
-      *reinterpret_cast<double2_t*>(lds + k * LDS_LD + 2 * xc) = r[q];
+      *reinterpret_cast<double2_t*>(lds + loff + q * (8 * LDS_LD * 8)) = r[q];
     } else {
-      const int xl = p & 15, kc = (p >> 4) & 7, xh = p >> 7;
-      lds[(2 * kc) * LDS_LD + xh * 16 + xl] = r[q].x;
-      lds[(2 * kc + 1) * LDS_LD + xh * 16 + xl] = r[q].y;
+      *reinterpret_cast<double*>(lds + loff + q * (32 * 8)) = r[q].x;
+      *reinterpret_cast<double*>(lds + loff + q * (32 * 8) + LDS_LD * 8) = r[q].y;
     }
   }
 }
@@ -87,7 +95,7 @@ __device__ __forceinline__ void tile_from_index(const GemmParams& p, int idx, in
 }
 
 template <bool A_KMAJOR, bool B_KMAJOR>
-__global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams p) {
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* As = smem;                   // [2][BK][LDS_LD]
   double* Bs = smem + 2 * OPER_ELEMS;  // [2][BK][LDS_LD]
@@ -95,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave >> 2, wc = wave & 3;  // 2 x 4 waves, 64 x 32 outputs each
 
   // XCD-aware remap: blocks b, b+8, b+16.. share an XCD (and its L2); give each XCD a contiguous
   // run of tile indices so neighbouring tiles (same A strip, adjacent B strips) hit in that L2.
@@ -107,9 +115,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams p) {
   }
   int ti, tj;
   tile_from_index(p, idx, ti, tj);
-  if (p.kmode == 2) {  // longest-K tiles (largest ti) first
-    ti = p.mt - 1 - ti;
-  }
+  if (p.kmode == 2) ti = p.mt - 1 - ti;  // longest-K tiles (largest ti) first
   const int i0 = ti * TILE, j0 = tj * TILE;
   int kbeg = 0, kend = p.k;
   if (p.kmode == 1) kbeg = j0;
@@ -120,85 +126,116 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams p) {
   const double* B = p.B + (long)blockIdx.z * p.strideB;
   double* C = p.C + (long)blockIdx.z * p.strideC;
 
-  double acc[4][4][4];
+  double4_t acc[4][2];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-      for (int s = 0; s < 4; ++s) acc[a][b][s] = 0.0;
+    for (int b = 0; b < 2; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
   const int nchunk = (kend - kbeg) / BK;
-  double2_t ra[4], rb[4];
+  unsigned gA, lA, gB, lB;
+  long sA, sB;
+  chunk_offsets<A_KMAJOR>(p.lda, tid, gA, lA, sA);
+  chunk_offsets<B_KMAJOR>(p.ldb, tid, gB, lB, sB);
+  // uniform chunk pointers (scalar registers)
+  const char* Ag = reinterpret_cast<const char*>(A_KMAJOR ? A + (long)kbeg * p.lda + i0 : A + (long)i0 * p.lda + kbeg);
+  const char* Bg = reinterpret_cast<const char*>(B_KMAJOR ? B + (long)kbeg * p.ldb + j0 : B + (long)j0 * p.ldb + kbeg);
+  const long stepA = (A_KMAJOR ? (long)BK * p.lda : (long)BK) * 8;
+  const long stepB = (B_KMAJOR ? (long)BK * p.ldb : (long)BK) * 8;
+  char* Asb = reinterpret_cast<char*>(As);
+  char* Bsb = reinterpret_cast<char*>(Bs);
+  double2_t ra[NQ], rb[NQ];
   if (nchunk > 0) {
-    chunk_load<A_KMAJOR>(A, p.lda, i0, kbeg, tid, ra);
-    chunk_load<B_KMAJOR>(B, p.ldb, j0, kbeg, tid, rb);
-    chunk_store<A_KMAJOR>(As, tid, ra);
-    chunk_store<B_KMAJOR>(Bs, tid, rb);
+    chunk_load(Ag, gA, sA, ra);
+    chunk_load(Bg, gB, sB, rb);
+    chunk_store<A_KMAJOR>(Asb, lA, ra);
+    chunk_store<B_KMAJOR>(Bsb, lB, rb);
   }
   __syncthreads();
 
-  // per-lane fragment offsets inside a chunk
-  const int kq = lane >> 4;                 // k within a k4 step
-  const int a_off = wr * 64 + (lane & 15);  // + 16*a
-  const int blk = (lane >> 2) & 3, jj = lane & 3;
-  int b_off[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) b_off[s] = wc * 64 + 4 * ((blk + s) & 3) + jj;  // + 16*b
+  // lane l of acc[a][b] holds rows 16a + (l>>4) + 4r (r = 0..3), column 16b + (l&15) of the wave's
+  // 64x32 sub-tile
+  const int kq = lane >> 4;  // k within a k4 step == row offset of the result
+  const int l15 = lane & 15;
+  const double* a_ptr = As + kq * LDS_LD + wr * 64 + l15;  // + 16*a
+  const double* b_ptr = Bs + kq * LDS_LD + wc * 32 + l15;  // + 16*b
 
-  for (int c = 0; c < nchunk; ++c) {
-    const int buf = c & 1;
-    const bool more = (c + 1 < nchunk);
+  double af[2][4], bf[2][2];  // register double buffer of the MFMA operands
+  auto load_frags = [&](int set, int boff, int kk) {
+    const double* ap = a_ptr + boff + kk * 4 * LDS_LD;
+    const double* bp = b_ptr + boff + kk * 4 * LDS_LD;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) af[set][a] = ap[16 * a];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) bf[set][b] = bp[16 * b];
+  };
+  // one K chunk: MFMAs on buffer boff while the next chunk travels global -> registers -> other buffer
+  auto chunk_iter = [&](int boff, bool more) {
+#ifndef EXP_NOLOAD
     if (more) {
-      chunk_load<A_KMAJOR>(A, p.lda, i0, kbeg + (c + 1) * BK, tid, ra);
-      chunk_load<B_KMAJOR>(B, p.ldb, j0, kbeg + (c + 1) * BK, tid, rb);
+      Ag += stepA;
+      Bg += stepB;
+      chunk_load(Ag, gA, sA, ra);
+      chunk_load(Bg, gB, sB, rb);
     }
-    const double* Ac = As + buf * OPER_ELEMS;
-    const double* Bc = Bs + buf * OPER_ELEMS;
+#endif
 #pragma unroll
     for (int kk = 0; kk < BK / 4; ++kk) {
-      const int krow = (kk * 4 + kq) * LDS_LD;
-      double af[4], bf[4][4];
-#pragma unroll
-      for (int a = 0; a < 4; ++a) af[a] = Ac[krow + a_off + 16 * a];
-#pragma unroll
-      for (int b = 0; b < 4; ++b)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) bf[b][s] = Bc[krow + b_off[s] + 16 * b];
+      const int cur = kk & 1;
+      if (kk + 1 < BK / 4) load_frags(cur ^ 1, boff, kk + 1);
+      // keep the next step's LDS reads ahead of this step's MFMAs (hipcc otherwise sinks them to
+      // their first use and every k4 step starts with an exposed LDS round trip)
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-          for (int s = 0; s < 4; ++s)
-            acc[a][b][s] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[a], bf[b][s], acc[a][b][s], 0, 0, 0);
-    }
-    if (more) {
-      chunk_store<A_KMAJOR>(As + (buf ^ 1) * OPER_ELEMS, tid, ra);
-      chunk_store<B_KMAJOR>(Bs + (buf ^ 1) * OPER_ELEMS, tid, rb);
-    }
-    __syncthreads();
-  }
-
-  // epilogue: C = beta*C + alpha*acc.  lane (i = l>>4, blk, j) of acc[a][b][s] is
-  // row 16a + 4blk + i, column 16b + 4((blk+s)&3) + j of the wave's 64x64 sub-tile.
-  const int ii = lane >> 4;
-  const double alpha = p.alpha, beta = p.beta;
-#pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    const long row = i0 + wr * 64 + 16 * a + 4 * blk + ii;
-    double* crow = C + row * p.ldc + j0 + wc * 64;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        double* cp = crow + 16 * b + 4 * ((blk + s) & 3) + jj;
-        double v = alpha * acc[a][b][s];
-        if (beta != 0.0) v += beta * (*cp);
-        *cp = v;
+        for (int b = 0; b < 2; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur][a], bf[cur][b], acc[a][b], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#ifndef EXP_STORE_KK
+#define EXP_STORE_KK (BK / 8)
+#endif
+      if (kk == EXP_STORE_KK && more) {
+        // the other buffer was last read in the previous iteration (behind its barrier): refill it now,
+        // well ahead of the barrier that publishes it
+        const int noff = (boff ^ OPER_ELEMS) * 8;
+        chunk_store<A_KMAJOR>(Asb + noff, lA, ra);
+        chunk_store<B_KMAJOR>(Bsb + noff, lB, rb);
       }
     }
+#ifndef EXP_NOBARRIER
+    __syncthreads();
+#endif
+    if (more) load_frags(0, boff ^ OPER_ELEMS, 0);
+  };
+
+  if (nchunk > 0) load_frags(0, 0, 0);
+  for (int c = 0; c + 1 < nchunk; ++c) chunk_iter((c & 1) * OPER_ELEMS, true);
+
+  // last chunk: fetch the C tile first so its latency hides under this chunk's MFMAs
+  const double alpha = p.alpha, beta = p.beta;
+  double* cbase = C + (long)(i0 + wr * 64 + kq) * p.ldc + j0 + wc * 32 + l15;
+  double4_t cv[4][2];
+  if (beta != 0.0) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cv[a][b][r] = cbase[(long)(16 * a + 4 * r) * p.ldc + 16 * b];
   }
+  if (nchunk > 0) chunk_iter(((nchunk - 1) & 1) * OPER_ELEMS, false);
+
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double v = alpha * acc[a][b][r];
+        if (beta != 0.0) v += beta * cv[a][b][r];
+        cbase[(long)(16 * a + 4 * r) * p.ldc + 16 * b] = v;
+      }
 }
 
 static int tile_count(const GemmParams& p) {
@@ -209,7 +246,7 @@ static int tile_count(const GemmParams& p) {
 hipError_t launch_gemm_f64(const GemmParams& p, int opA_kmajor, int opB_kmajor, int batch, hipStream_t stream) {
   const int nblk = tile_count(p);
   if (nblk <= 0 || batch <= 0) return hipSuccess;
-  dim3 grid(nblk, 1, batch), block(256);
+  dim3 grid(nblk, 1, batch), block(NTHREADS);
   const size_t lds = sizeof(double) * 4 * OPER_ELEMS;
   if (!opA_kmajor && !opB_kmajor) gemm_f64_kernel<false, false><<<grid, block, lds, stream>>>(p);
   else if (!opA_kmajor && opB_kmajor) gemm_f64_kernel<false, true><<<grid, block, lds, stream>>>(p);

@@ -13,7 +13,7 @@ struct GemmParams {
   long lda, ldb, ldc;
   long strideA, strideB, strideC;  // batch strides in elements (blockIdx.z)
   int mt, nt;                      // output tiles (128 x 128) in rows / columns
-  int k;                           // contraction length, multiple of 16
+  int k;                           // contraction length, multiple of 32
   int tri;                         // 1: only tiles with tj <= min(ti, nt-1)  (SYRK / trapezoid)
   int kmode;                       // 0 full k; 1 k >= tj*128; 2 k < (ti+1)*128; 3 k >= ti*128
   double alpha, beta;

@@ -17,7 +17,7 @@ dev = torch.device("cuda:0")
 torch.manual_seed(0)
 ok = True
 for (ta, tb) in [(0, 1), (0, 0), (1, 0), (1, 1)]:
-    m, n, k = 256, 384, 80
+    m, n, k = 256, 384, 96
     A = torch.randn((k, m) if ta else (m, k), dtype=torch.float64, device=dev)
     B = torch.randn((n, k) if tb else (k, n), dtype=torch.float64, device=dev)
     C = torch.randn(m, n, dtype=torch.float64, device=dev)

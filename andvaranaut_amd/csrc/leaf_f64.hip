@@ -17,6 +17,37 @@ constexpr int LEAF = 128;
 constexpr int LEAF_LD = 130;  // LDS leading dimension (rows stay 16-byte aligned)
 constexpr int SB = 16;        // sub-block width
 
+// 1/sqrt(x) for normal positive x: hardware seed (v_rsq_f64) + two Goldschmidt steps + one
+// Newton correction; ~1 ulp, about 15 dependent FMAs instead of the ~80-instruction
+// correctly-rounded sqrt + divide sequence (which dominated the per-pivot latency of the leaf).
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  r = __builtin_fma(-h, g, 0.5);
+  h = __builtin_fma(h, r, h);
+  double inv = h + h;
+  const double t = __builtin_fma(-x * inv, inv, 1.0);
+  return __builtin_fma(0.5 * inv, t, inv);
+}
+
+#ifdef LEAF_STAMPS
+__device__ unsigned long long g_leaf_stamps[8];
+#define LEAF_STAMP(i)                                                                  \
+  do {                                                                                 \
+    if (threadIdx.x == 0) {                                                            \
+      unsigned long long t_;                                                           \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");        \
+      g_leaf_stamps[i] += t_ - t_prev;                                                 \
+      t_prev = t_;                                                                     \
+    }                                                                                  \
+  } while (0)
+#else
+#define LEAF_STAMP(i)
+#endif
+
 __device__ __forceinline__ void wave_lds_fence() {
   // order this wave's LDS writes before its later LDS reads (DS ops execute in order per wave;
   // this only stops the compiler from reordering / caching across the point)
@@ -24,137 +55,226 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// 1/x for normal x: hardware seed (v_rcp_f64) + two Newton steps (~1 ulp).
+__device__ __forceinline__ double fast_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-x, y, 1.0);
+  return __builtin_fma(y, e, y);
+}
+
+// broadcast lane `src`'s double to the whole wave through scalar registers (v_readlane_b32 x 2)
+__device__ __forceinline__ double bcast_lane(double v, int src) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = __builtin_amdgcn_readlane((int)(u & 0xffffffffu), src);
+  const unsigned hi = __builtin_amdgcn_readlane((int)(u >> 32), src);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+// acc += bcast(src from lane C of each 16-lane row) * mul   -- one instruction: v_fmac_f64 with the
+// DPP row_newbcast control (the only DPP form fp64 VALU ops have on gfx90a+).  hipcc cannot see the
+// "VALU write -> DPP read of the same VGPR" hazard (2 wait states) inside inline asm: callers must
+// not pass a `src` written by the immediately preceding VALU instruction (mov_rowbcast pads itself).
+template <int C>
+__device__ __forceinline__ void fmac_rowbcast(double& acc, double src, double mul) {
+  asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+               : "+v"(acc)
+               : "v"(src), "v"(mul), "n"(C));
+}
+template <int C>
+__device__ __forceinline__ double mov_rowbcast(double src) {
+  double out;
+  asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf"
+               : "=v"(out)
+               : "v"(src), "n"(C));
+  return out;
+}
+
+// One elimination step of the 16x16 diagonal sub-block held one row per lane (a[c], c = 0..15):
+// square-root-free form, a_rc -= (a_rj / p_j) * a_cj for c > j, column j+1 first so that the next
+// pivot's reciprocal chain starts as early as possible.
+template <int J, int C>
+struct ElimCols {
+  static __device__ __forceinline__ void run(double (&a)[16], double negw) {
+    fmac_rowbcast<C>(a[C], a[J], negw);
+    ElimCols<J, C + 1>::run(a, negw);
+  }
+};
+template <int J>
+struct ElimCols<J, 16> {
+  static __device__ __forceinline__ void run(double (&)[16], double) {}
+};
+template <int J>
+struct ElimStep {
+  static __device__ __forceinline__ void run(double (&a)[16], double p, int& bad) {
+    if (!(p > 0.0) && bad == 0) bad = J + 1;
+    const double negw = -a[J] * fast_rcp(p);
+    fmac_rowbcast<J + 1>(a[J + 1], a[J], negw);
+    const double pn = mov_rowbcast<J + 1>(a[J + 1]);
+    ElimCols<J, J + 2>::run(a, negw);
+    ElimStep<J + 1>::run(a, pn, bad);
+  }
+};
+template <>
+struct ElimStep<15> {
+  static __device__ __forceinline__ void run(double (&)[16], double p, int& bad) {
+    if (!(p > 0.0) && bad == 0) bad = 16;
+  }
+};
+template <int C>
+struct ScaleCols {
+  static __device__ __forceinline__ void run(const double (&a)[16], double rs, double (&l)[16]) {
+    l[C] = a[C] * mov_rowbcast<C>(rs);
+    ScaleCols<C + 1>::run(a, rs, l);
+  }
+};
+template <>
+struct ScaleCols<16> {
+  static __device__ __forceinline__ void run(const double (&)[16], double, double (&)[16]) {}
+};
+
 // info: 0 = ok, else 1-based global index of the first non-positive (or NaN) pivot (atomicMin'd).
+//
+// Structure per 16-column block jb of the 128x128 leaf (all of it LDS resident):
+//  (A) wave 0 factors the 16x16 diagonal sub-block in REGISTERS: lane r owns row r, columns are
+//      eliminated in square-root-free (LDL^T) form so the per-pivot critical path is
+//      row-broadcast -> rcp -> mul -> fma (the rsqrt of all 16 pivots is taken once, in parallel, at
+//      the end); column values are broadcast inside v_fmac_f64_dpp row_newbcast, so one elimination
+//      is ONE instruction and there is no LDS round trip per pivot;
+//  (B) rows below: X = B L16^-T, one thread per row, column-oriented substitution in registers;
+//  (C) trailing update of the remaining lower tiles on fp64 MFMA (rank 16).
 __global__ __launch_bounds__(256, 1) void potrf_leaf128_kernel(double* __restrict__ Ablk, long lda,
                                                                 double* __restrict__ dinv, int col0,
                                                                 int* __restrict__ info) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  double* S = smem;                          // [128][LEAF_LD]
-  double* Ld = smem + LEAF * LEAF_LD;        // [16][17] factored diagonal sub-block
-  double* invd = Ld + SB * 17;               // [128] 1 / L[c][c]
+  double* S = smem;                     // [128][LEAF_LD]
+  double* LdT = smem + LEAF * LEAF_LD;  // [16][16]  LdT[k][c] = L16[c][k] (current diagonal sub-block)
+  double* invd = LdT + SB * SB;         // [128] 1 / L[c][c]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
+#ifdef LEAF_STAMPS
+  unsigned long long t_prev = 0;
+  if (threadIdx.x == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory");
+#endif
 
-  // load the lower triangle (whole rows up to the diagonal's 16-block, coalesced along rows)
-  for (int e = tid; e < LEAF * (LEAF / 2); e += 256) {
-    const int r = e >> 6, c2 = (e & 63) * 2;
-    if (c2 <= r) {
-      const double* src = Ablk + (long)r * lda + c2;
-      S[r * LEAF_LD + c2] = src[0];
-      S[r * LEAF_LD + c2 + 1] = src[1];
+  // load the whole 128x128 block (the strict upper triangle is never used), 16 B per lane per load
+  {
+    typedef double double2_t __attribute__((ext_vector_type(2)));
+    double2_t v[8];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int e = tid + 256 * (q + 8 * h);  // 16-byte piece index: row = e >> 6, col pair = e & 63
+        v[q] = *reinterpret_cast<const double2_t*>(Ablk + (long)(e >> 6) * lda + 2 * (e & 63));
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int e = tid + 256 * (q + 8 * h);
+        *reinterpret_cast<double2_t*>(S + (e >> 6) * LEAF_LD + 2 * (e & 63)) = v[q];
+      }
     }
   }
   __syncthreads();
+  LEAF_STAMP(0);
 
   for (int jb = 0; jb < LEAF / SB; ++jb) {
     const int j0 = jb * SB;
-    // ---- (A) factor the 16x16 diagonal sub-block: wave 0, right-looking, column at a time
+    // ---- (A) 16x16 diagonal sub-block in registers (wave 0; lanes 16..63 mirror lanes 0..15)
     if (wave == 0) {
-      const int r = lane & 15, g = lane >> 4;
-      for (int j = 0; j < SB; ++j) {
-        const double p = S[(j0 + j) * LEAF_LD + j0 + j];
-        if (!(p > 0.0)) {
-          if (lane == 0) atomicMin(info, col0 + j0 + j + 1);
-        }
-        const double inv = 1.0 / sqrt(p);
-        const double arj = S[(j0 + r) * LEAF_LD + j0 + j];
-        const double inv2 = inv * inv;
+      const int r = lane & 15;
+      double a[SB];
+      {
+        const double* row = S + (j0 + r) * LEAF_LD + j0;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int c = g + 4 * t;
-          if (c > j && c <= r) {
-            const double acj = S[(j0 + c) * LEAF_LD + j0 + j];
-            S[(j0 + r) * LEAF_LD + j0 + c] -= arj * acj * inv2;
-          }
-        }
-        if (g == 0) {
-          if (r > j) Ld[r * 17 + j] = arj * inv;
-          else if (r == j) { Ld[r * 17 + j] = p * inv; invd[j0 + j] = inv; }
-        }
-        wave_lds_fence();
+        for (int c = 0; c < SB; ++c) a[c] = row[c];
       }
+      int bad = 0;
+      ElimStep<0>::run(a, mov_rowbcast<0>(a[0]), bad);
+      if (bad != 0 && lane == 0) atomicMin(info, col0 + j0 + bad);
+      // normalise: L[r][c] = a[c] * rsqrt(p_c); lane c holds p_c = a[c]
+      const double rs = fast_rsqrt(a[r]);
+      double l[SB];
+      ScaleCols<0>::run(a, rs, l);
+      double* row = S + (j0 + r) * LEAF_LD + j0;
+#pragma unroll
+      for (int c = 0; c < SB; ++c) {
+        if (lane < SB && c <= r) {
+          row[c] = l[c];
+          LdT[c * SB + r] = l[c];
+        }
+      }
+      if (lane < SB) invd[j0 + r] = rs;
     }
     __syncthreads();
-    // ---- (B) rows below: X = B * L16^-T by forward substitution, one thread per row;
-    //          rows inside the diagonal sub-block just copy the factor back into S
+    LEAF_STAMP(1);
+    // ---- (B) rows below: X = B * L16^-T, one thread per row, column-oriented forward substitution
     {
-      const int nrow = LEAF - j0;  // rows j0 .. 127
+      const int nrow = LEAF - j0 - SB;  // rows j0+16 .. 127
       if (tid < nrow) {
-        const int r = j0 + tid;
-        double* row = S + r * LEAF_LD + j0;
-        if (tid < SB) {
-          for (int c = 0; c <= tid; ++c) row[c] = Ld[tid * 17 + c];
-        } else {
-          double x[SB];
+        double* row = S + (j0 + SB + tid) * LEAF_LD + j0;
+        double x[SB];
 #pragma unroll
-          for (int c = 0; c < SB; ++c) x[c] = row[c];
+        for (int c = 0; c < SB; ++c) x[c] = row[c];
 #pragma unroll
-          for (int c = 0; c < SB; ++c) {
-            double s = x[c];
+        for (int k = 0; k < SB; ++k) {
+          x[k] *= invd[j0 + k];
 #pragma unroll
-            for (int k = 0; k < c; ++k) s -= x[k] * Ld[c * 17 + k];
-            x[c] = s * invd[j0 + c];
+          for (int c = k + 1; c < SB; ++c) x[c] = __builtin_fma(-x[k], LdT[k * SB + c], x[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < SB; ++c) row[c] = x[c];
+      }
+    }
+    __syncthreads();
+    LEAF_STAMP(2);
+    // ---- (C) trailing update S[i-tile][c-tile] -= X_i X_c^T on fp64 MFMA (rank 16), lower tiles only
+    {
+      const int q = LEAF / SB - 1 - jb;  // trailing tiles per dimension
+      const int n = lane & 15, kq = lane >> 4;
+      int e = 0;
+      for (int tr = 0; tr < q; ++tr) {
+        for (int tc = 0; tc <= tr; ++tc, ++e) {
+          if ((e & 3) != wave) continue;
+          const int r0 = j0 + SB + 16 * tr, c0 = j0 + SB + 16 * tc;
+          double4_t acc;
+          double av[4], bv[4];
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) {
+            av[s4] = S[(r0 + n) * LEAF_LD + j0 + 4 * s4 + kq];  // X[r0 + (l&15)][k = 4s + (l>>4)]
+            bv[s4] = S[(c0 + n) * LEAF_LD + j0 + 4 * s4 + kq];  // X[c0 + (l&15)][k]
           }
 #pragma unroll
-          for (int c = 0; c < SB; ++c) row[c] = x[c];
+          for (int r = 0; r < 4; ++r) acc[r] = S[(r0 + kq + 4 * r) * LEAF_LD + c0 + n];
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[s4], bv[s4], acc, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) S[(r0 + kq + 4 * r) * LEAF_LD + c0 + n] = acc[r];
         }
       }
     }
     __syncthreads();
-    // ---- (C) trailing update S[r][c] -= sum_k X[r][k] X[c][k], 4x4 micro-tiles, lower part only
-    {
-      const int t0 = j0 + SB;
-      const int q = (LEAF - t0) / 4;  // micro-tiles per dimension
-      const int nt = q * (q + 1) / 2;
-      for (int e = tid; e < nt; e += 256) {
-        int tr = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
-        while ((tr + 1) * (tr + 2) / 2 <= e) ++tr;
-        while (tr * (tr + 1) / 2 > e) --tr;
-        const int tc = e - tr * (tr + 1) / 2;
-        const int r0 = t0 + 4 * tr, c0 = t0 + 4 * tc;
-        double acc[4][4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-          for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
-#pragma unroll
-        for (int kc = 0; kc < SB; kc += 4) {
-          double xr[4][4], xc[4][4];
-#pragma unroll
-          for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              xr[a][k] = S[(r0 + a) * LEAF_LD + j0 + kc + k];
-              xc[a][k] = S[(c0 + a) * LEAF_LD + j0 + kc + k];
-            }
-#pragma unroll
-          for (int k = 0; k < 4; ++k)
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-              for (int b = 0; b < 4; ++b) acc[a][b] += xr[a][k] * xc[b][k];
-        }
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-          for (int b = 0; b < 4; ++b) S[(r0 + a) * LEAF_LD + c0 + b] -= acc[a][b];
-      }
-    }
-    __syncthreads();
+    LEAF_STAMP(3);
   }
 
-  // ---- write L back (lower triangle incl. diagonal)
-  for (int e = tid; e < LEAF * (LEAF / 2); e += 256) {
-    const int r = e >> 6, c2 = (e & 63) * 2;
-    double* dst = Ablk + (long)r * lda + c2;
-    if (c2 + 1 <= r) {
-      dst[0] = S[r * LEAF_LD + c2];
-      dst[1] = S[r * LEAF_LD + c2 + 1];
-    } else if (c2 == r) {
-      dst[0] = S[r * LEAF_LD + c2];
+  // ---- write L back (whole rows up to and including the diagonal's pair; upper part is don't-care)
+  {
+    typedef double double2_t __attribute__((ext_vector_type(2)));
+#pragma unroll 8
+    for (int it = 0; it < 32; ++it) {
+      const int e = tid + 256 * it;
+      const int r = e >> 6, c2 = 2 * (e & 63);
+      if (c2 <= r) {
+        const double2_t v = *reinterpret_cast<const double2_t*>(S + r * LEAF_LD + c2);
+        double* dst = Ablk + (long)r * lda + c2;
+        if (c2 + 1 <= r) *reinterpret_cast<double2_t*>(dst) = v;
+        else dst[0] = v.x;
+      }
     }
   }
+  LEAF_STAMP(4);
   // ---- inverses of the eight 16x16 diagonal sub-blocks: thread (b, c) solves column c of block b
   if (tid < LEAF) {
     const int b = tid >> 4, c = tid & 15, j0 = b * SB;
@@ -163,19 +283,20 @@ __global__ __launch_bounds__(256, 1) void potrf_leaf128_kernel(double* __restric
     for (int r = 0; r < SB; ++r) z[r] = 0.0;
 #pragma unroll
     for (int r = 0; r < SB; ++r) {
-      if (r == c) z[r] = invd[j0 + r];
-      else if (r > c) {
-        double s = 0.0;
+      const double* lrow = S + (j0 + r) * LEAF_LD + j0;
+      double s0 = (r == c) ? 1.0 : 0.0, s1 = 0.0;
 #pragma unroll
-        for (int k = 0; k < r; ++k)
-          if (k >= c) s -= S[(j0 + r) * LEAF_LD + j0 + k] * z[k];
-        z[r] = s * invd[j0 + r];
+      for (int k = 0; k < r; ++k) {  // z[k] = 0 for k < c, so no predicate is needed
+        if (k & 1) s1 = __builtin_fma(-lrow[k], z[k], s1);
+        else s0 = __builtin_fma(-lrow[k], z[k], s0);
       }
+      z[r] = (r >= c) ? (s0 + s1) * invd[j0 + r] : 0.0;
     }
     double* out = dinv + (long)b * SB * SB;
 #pragma unroll
     for (int r = 0; r < SB; ++r) out[r * SB + c] = z[r];
   }
+  LEAF_STAMP(5);
 }
 
 // X * L^T = B, in place on B (m x 128, leading dimension ldb, m multiple of 64).
@@ -232,7 +353,7 @@ __global__ __launch_bounds__(256, 1) void trsm_strip128_kernel(const double* __r
     for (int r = 0; r < 4; ++r) Brow[16 * j + 4 * r + q] = T[j][r];
 }
 
-constexpr size_t LEAF_LDS_BYTES = sizeof(double) * (LEAF * LEAF_LD + SB * 17 + LEAF);
+constexpr size_t LEAF_LDS_BYTES = sizeof(double) * (LEAF * LEAF_LD + SB * SB + LEAF);
 constexpr size_t STRIP_LDS_BYTES = sizeof(double) * (LEAF * LEAF_LD);
 
 hipError_t leaf_enable_lds() {

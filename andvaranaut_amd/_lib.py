@@ -63,6 +63,9 @@ def load():
     lib.mi_gp_set_data.argtypes = [vp, ctypes.POINTER(MiGpBuffers)]
     lib.mi_gp_lml.argtypes = [vp, dp, dp]
     lib.mi_gp_lml_parts.argtypes = [vp, dp, dp]
+    lib.mi_gp_lml_grad.argtypes = [vp, dp, dp, dp]
+    lib.mi_gp_factor.argtypes = [vp, dp]
+    lib.mi_gp_predict.argtypes = [vp, vp, ci, vp, cl, vp, vp, ci]
     lib.mi_gp_set_profiling.argtypes = [vp, ci]
     lib.mi_gp_timers.argtypes = [vp, dp, ci]
     lib.mi_gp_gemm_f64.argtypes = [ci, ci, ci, ci, ci, cd, vp, cl, vp, cl, cd, vp, cl, ci, ci, ci, cl, cl, cl, vp]
@@ -84,6 +87,9 @@ EXPORTS = [
     "mi_gp_set_data",
     "mi_gp_lml",
     "mi_gp_lml_parts",
+    "mi_gp_lml_grad",
+    "mi_gp_factor",
+    "mi_gp_predict",
     "mi_gp_set_profiling",
     "mi_gp_timers",
     "mi_gp_gemm_f64",

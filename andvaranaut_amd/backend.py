@@ -104,13 +104,60 @@ class MiGP:
         self.lib.mi_gp_lml_parts(self.h, ctypes.byref(a), ctypes.byref(b))
         return a.value, b.value
 
+    def lml_grad(self, theta):
+        """(LML, dLML/dtheta) at natural-scale theta; (-inf, zeros) if K is not positive definite."""
+        if self.Z_t is None:
+            raise RuntimeError("this MiGP was created with need_grad=False")
+        theta, tp = self._theta(theta)
+        out = ctypes.c_double()
+        grad = np.zeros(self.ntheta)
+        gp_ = grad.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+        self.info = self._check(self.lib.mi_gp_lml_grad(self.h, tp, ctypes.byref(out), gp_), "mi_gp_lml_grad")
+        return out.value, grad
+
+    def factor(self, theta):
+        """Factorise for prediction (conditional form); returns LAPACK-style info."""
+        theta, tp = self._theta(theta)
+        self.info = self._check(self.lib.mi_gp_factor(self.h, tp), "mi_gp_factor")
+        return self.info
+
+    def predict(self, theta, Xnew, pred_noise=True, chunk=16384):
+        """Posterior mean and diagonal variance at Xnew (converted inputs), chunked over points."""
+        if self.factor(theta) != 0:
+            raise FloatingPointError(f"covariance not positive definite at pivot {self.info}")
+        Xnew = np.ascontiguousarray(Xnew, dtype=np.float64)
+        if Xnew.ndim != 2 or Xnew.shape[1] != self.d:
+            raise ValueError("Xnew must be (m, d)")
+        m = Xnew.shape[0]
+        mean = np.empty(m)
+        var = np.empty(m)
+        with torch.cuda.device(self.dev):
+            for s in range(0, m, chunk):
+                mc = min(chunk, m - s)
+                mp = (mc + 127) // 128 * 128
+                if getattr(self, "_work", None) is None or self._work.shape[0] < mp:
+                    self._work = torch.empty((mp, self.lda), dtype=torch.float64, device=self.dev)
+                xn = torch.from_numpy(Xnew[s : s + mc]).to(self.dev)
+                mu_t = torch.empty(mc, dtype=torch.float64, device=self.dev)
+                var_t = torch.empty(mc, dtype=torch.float64, device=self.dev)
+                torch.cuda.synchronize(self.dev)
+                self._check(
+                    self.lib.mi_gp_predict(self.h, xn.data_ptr(), mc, self._work.data_ptr(), self.lda, mu_t.data_ptr(),
+                                           var_t.data_ptr(), 1 if pred_noise else 0),
+                    "mi_gp_predict",
+                )
+                mean[s : s + mc] = mu_t.cpu().numpy()
+                var[s : s + mc] = var_t.cpu().numpy()
+        return mean, var
+
     def set_profiling(self, level):
         self.lib.mi_gp_set_profiling(self.h, int(level))
 
     def timers(self):
-        out = (ctypes.c_double * 7)()
-        self.lib.mi_gp_timers(self.h, out, 7)
-        keys = ["assemble_ms", "cholesky_ms", "reduce_ms", "total_ms", "gemm_ms", "gemm_flops", "gemm_launches"]
+        out = (ctypes.c_double * 10)()
+        self.lib.mi_gp_timers(self.h, out, 10)
+        keys = ["assemble_ms", "cholesky_ms", "reduce_ms", "total_ms", "gemm_ms", "gemm_flops", "gemm_launches",
+                "trtri_ms", "lauum_ms", "contract_ms"]
         return dict(zip(keys, list(out)))
 
     def close(self):

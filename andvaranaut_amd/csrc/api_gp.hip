@@ -23,6 +23,10 @@ struct mi_gp_handle {
   double* theta_dev;    // [ntheta]
   double* out_dev;      // [16] scalars
   double* dinv_dev;     // [ntc][8][16][16]
+  double* alpha_dev;    // [np] K^-1 y
+  double* part_dev;     // [grad_contract_blocks(n)][ntheta]
+  double* grad_dev;     // [ntheta]
+  double* grad_host;    // pinned [ntheta]
   int* info_dev;
   double* out_host;     // pinned [16]
   int* info_host;       // pinned
@@ -34,6 +38,8 @@ struct mi_gp_handle {
   size_t gemm_ev_used;
   double gemm_flops_acc;
   double t_assemble_ms, t_chol_ms, t_reduce_ms, t_gemm_ms, t_total_ms, gemm_flops, n_gemm;
+  double t_trtri_ms, t_lauum_ms, t_contract_ms;
+  bool factored;
   char err[256];
 };
 
@@ -69,6 +75,8 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   h->ntheta = cfg->nkern * cfg->d + 2 * cfg->nkern + 2;
   h->device = cfg->device;
   h->have_data = false;
+  h->factored = false;
+  h->t_trtri_ms = h->t_lauum_ms = h->t_contract_ms = 0.0;
   h->prof_level = 0;
   h->gemm_ev_used = 0;
   hipError_t e = hipSetDevice(h->device);
@@ -76,6 +84,10 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   if (e == hipSuccess) e = hipMalloc(&h->theta_dev, sizeof(double) * h->ntheta);
   if (e == hipSuccess) e = hipMalloc(&h->out_dev, sizeof(double) * 16);
   if (e == hipSuccess) e = hipMalloc(&h->dinv_dev, sizeof(double) * 2048 * (size_t)h->ntc);
+  if (e == hipSuccess) e = hipMalloc(&h->alpha_dev, sizeof(double) * h->np);
+  if (e == hipSuccess) e = hipMalloc(&h->part_dev, sizeof(double) * (size_t)grad_contract_blocks(h->n) * h->ntheta);
+  if (e == hipSuccess) e = hipMalloc(&h->grad_dev, sizeof(double) * h->ntheta);
+  if (e == hipSuccess) e = hipHostMalloc(&h->grad_host, sizeof(double) * h->ntheta);
   if (e == hipSuccess) e = hipMalloc(&h->info_dev, sizeof(int) * 4);
   if (e == hipSuccess) e = hipHostMalloc(&h->out_host, sizeof(double) * 16);
   if (e == hipSuccess) e = hipHostMalloc(&h->info_host, sizeof(int) * 4);
@@ -98,6 +110,7 @@ extern "C" int mi_gp_destroy(mi_gp_handle* h) {
   hipSetDevice(h->device);
   hipStreamSynchronize(h->stream);
   hipFree(h->theta_dev); hipFree(h->out_dev); hipFree(h->dinv_dev); hipFree(h->info_dev);
+  hipFree(h->alpha_dev); hipFree(h->part_dev); hipFree(h->grad_dev); hipHostFree(h->grad_host);
   hipHostFree(h->out_host); hipHostFree(h->info_host); hipHostFree(h->theta_host);
   for (int i = 0; i < 8; ++i) hipEventDestroy(h->ev[i]);
   for (auto& ev : h->gemm_ev) hipEventDestroy(ev);
@@ -191,7 +204,7 @@ static hipError_t chol_panel(mi_gp_handle* h, double* A, long lda, int ntr, int 
 }
 
 static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int ntc) {
-  int W = h->cfg.panel_tiles > 0 ? h->cfg.panel_tiles : 2;
+  int W = h->cfg.panel_tiles > 0 ? h->cfg.panel_tiles : 4;
   for (int J = 0; J < ntc; J += W) {
     const int w = (ntc - J < W) ? (ntc - J) : W;
     hipError_t e = chol_panel(h, A, lda, ntr, J, w);
@@ -215,6 +228,7 @@ static int upload_theta(mi_gp_handle* h, const double* theta) {
 
 // assemble + factor the augmented trapezoid [[K],[y^T]]; leaves L in K_dev, beta = L^-1 y in row np
 static int factor_internal(mi_gp_handle* h, const double* theta, int noise_form) {
+  h->factored = false;
   if (!h->have_data) { snprintf(h->err, sizeof(h->err), "mi_gp_set_data has not been called"); return -1; }
   HCK(hipSetDevice(h->device), "hipSetDevice");
   if (int r = upload_theta(h, theta)) return r;
@@ -270,10 +284,148 @@ extern "C" int mi_gp_lml_parts(mi_gp_handle* h, double* logdet, double* quad) {
   return 0;
 }
 
-// out: [assemble_ms, chol_ms, reduce_ms, total_ms, gemm_ms, gemm_flops, n_gemm_launches]
+// out: [assemble_ms, chol_ms, reduce_ms, total_ms, gemm_ms, gemm_flops, n_gemm_launches,
+//       trtri_ms, lauum_ms, contract_ms]
 extern "C" int mi_gp_timers(mi_gp_handle* h, double* out, int n) {
   if (!h || !out) return -1;
-  const double v[7] = {h->t_assemble_ms, h->t_chol_ms, h->t_reduce_ms, h->t_total_ms, h->t_gemm_ms, h->gemm_flops, h->n_gemm};
-  for (int i = 0; i < n && i < 7; ++i) out[i] = v[i];
+  const double v[10] = {h->t_assemble_ms, h->t_chol_ms, h->t_reduce_ms, h->t_total_ms, h->t_gemm_ms, h->gemm_flops,
+                        h->n_gemm, h->t_trtri_ms, h->t_lauum_ms, h->t_contract_ms};
+  for (int i = 0; i < n && i < 10; ++i) out[i] = v[i];
+  return 0;
+}
+
+// ---------------------------------------------------------------- gradient (K7)
+// U = L^-T (upper triangular, row-major in Z_dev) by leaf solves + level-batched block doubling:
+//   [[L11, 0], [L21, L22]]^-T = [[U11, -U11 L21^T U22], [0, U22]]
+// then Kinv = U U^T (lower tiles, W_dev), alpha = U beta, and the contraction kernel.
+static hipError_t gemm_call(mi_gp_handle* h, int ak, int bk, const double* A, long lda, long sA, const double* B, long ldb,
+                            long sB, double* C, long ldc, long sC, int mt, int nt, int k, int tri, int kmode,
+                            double alpha, double beta, int batch) {
+  GemmParams p;
+  p.A = A; p.B = B; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.strideA = sA; p.strideB = sB; p.strideC = sC;
+  p.mt = mt; p.nt = nt; p.k = k; p.tri = tri; p.kmode = kmode; p.alpha = alpha; p.beta = beta;
+  return launch_gemm_f64(p, ak, bk, batch, h->stream);
+}
+
+static hipError_t inverse_transpose(mi_gp_handle* h) {
+  const double* L = h->buf.K_dev;
+  double* U = h->buf.Z_dev;
+  double* T = h->buf.W_dev;
+  const long ld = h->buf.lda;
+  const int ntc = h->ntc;
+  hipError_t e = launch_set_identity_blocks(U, ld, ntc, h->stream);
+  if (e != hipSuccess) return e;
+  // leaves: X L_kk^T = I  ->  X = L_kk^-T
+  e = launch_trsm_strip128_batched(L, ld, 128 * ld + 128, h->dinv_dev, U, ld, 128 * ld + 128, 128, ntc, h->stream);
+  if (e != hipSuccess) return e;
+  for (int s = 1; s < ntc; s *= 2) {
+    const int nfull = ntc / (2 * s);             // nodes whose second half is complete
+    const int rem = ntc - nfull * 2 * s;         // tiles left for a trailing partial node
+    const long node = (long)2 * s * 128 * (ld + 1);
+    for (int pass = 0; pass < 2; ++pass) {
+      int batch, s2;
+      long off;
+      if (pass == 0) { batch = nfull; s2 = s; off = 0; }
+      else { batch = (rem > s) ? 1 : 0; s2 = rem - s; off = (long)nfull * node; }
+      if (batch == 0) continue;
+      const double* U11 = U + off;
+      const double* U22 = U + off + (long)s * 128 * (ld + 1);
+      const double* L21 = L + off + (long)s * 128 * ld;
+      double* P = T + off + (long)s * 128;
+      double* U12 = U + off + (long)s * 128;
+      // P = U11 L21^T   (U11 upper triangular: k >= row tile)
+      e = gemm_call(h, 0, 0, U11, ld, node, L21, ld, node, P, ld, node, s, s2, s * 128, 0, 3, 1.0, 0.0, batch);
+      if (e != hipSuccess) return e;
+      // U12 = -P U22    (U22 upper triangular: k <= column tile)
+      e = gemm_call(h, 0, 1, P, ld, node, U22, ld, node, U12, ld, node, s, s2, s2 * 128, 0, 4, -1.0, 0.0, batch);
+      if (e != hipSuccess) return e;
+    }
+  }
+  return hipSuccess;
+}
+
+extern "C" int mi_gp_lml_grad(mi_gp_handle* h, const double* theta, double* lml_out, double* grad_out) {
+  if (!h || !theta || !lml_out || !grad_out) return -1;
+  if (!h->buf.Z_dev || !h->buf.W_dev) {
+    snprintf(h->err, sizeof(h->err), "mi_gp_lml_grad needs Z_dev and W_dev in mi_gp_set_data");
+    return -1;
+  }
+  const int r = factor_internal(h, theta, 0);
+  if (r < 0) return r;
+  for (int i = 0; i < h->ntheta; ++i) grad_out[i] = 0.0;
+  if (r > 0) { *lml_out = -INFINITY; return r; }
+  *lml_out = h->out_host[0];
+  const bool prof = h->prof_level >= 1;
+  if (prof) hipEventRecord(h->ev[4], h->stream);
+  HCK(inverse_transpose(h), "inverse_transpose");
+  if (prof) hipEventRecord(h->ev[5], h->stream);
+  const long ld = h->buf.lda;
+  // Kinv = U U^T, lower tiles only, k >= row tile
+  HCK(gemm_call(h, 0, 0, h->buf.Z_dev, ld, 0, h->buf.Z_dev, ld, 0, h->buf.W_dev, ld, 0, h->ntc, h->ntc, h->np, 1, 3, 1.0,
+                0.0, 1), "lauum");
+  if (prof) hipEventRecord(h->ev[6], h->stream);
+  HCK(launch_trmv_upper(h->buf.Z_dev, ld, h->buf.K_dev + (long)h->np * ld, h->n, h->alpha_dev, h->stream), "trmv");
+  HCK(launch_grad_contract(h->spec, h->theta_dev, h->buf.X_dev, h->n, h->buf.W_dev, ld, h->alpha_dev, h->part_dev,
+                           h->grad_dev, h->stream), "grad_contract");
+  if (prof) hipEventRecord(h->ev[7], h->stream);
+  HCK(hipMemcpyAsync(h->grad_host, h->grad_dev, sizeof(double) * h->ntheta, hipMemcpyDeviceToHost, h->stream), "grad download");
+  HCK(hipStreamSynchronize(h->stream), "stream sync");
+  for (int i = 0; i < h->ntheta; ++i) grad_out[i] = h->grad_host[i];
+  if (prof) {
+    float ms;
+    hipEventElapsedTime(&ms, h->ev[4], h->ev[5]); h->t_trtri_ms = ms;
+    hipEventElapsedTime(&ms, h->ev[5], h->ev[6]); h->t_lauum_ms = ms;
+    hipEventElapsedTime(&ms, h->ev[6], h->ev[7]); h->t_contract_ms = ms;
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------- conditional (K8)
+extern "C" int mi_gp_factor(mi_gp_handle* h, const double* theta) {
+  if (!h || !theta) return -1;
+  const int r = factor_internal(h, theta, 1);
+  h->factored = (r == 0);
+  return r;
+}
+
+// solve X L^T = B in place for tile columns [c0, c0+w) of the mp x np work matrix
+static hipError_t trsm_rec(mi_gp_handle* h, double* Bw, long ldw, int mp, int c0, int w) {
+  const double* L = h->buf.K_dev;
+  const long lda = h->buf.lda;
+  if (w == 1) {
+    return launch_trsm_strip128(L + (long)c0 * 128 * lda + (long)c0 * 128, lda, h->dinv_dev + (size_t)c0 * 2048,
+                                Bw + (long)c0 * 128, ldw, mp, h->stream);
+  }
+  const int w1 = w / 2, w2 = w - w1;
+  hipError_t e = trsm_rec(h, Bw, ldw, mp, c0, w1);
+  if (e != hipSuccess) return e;
+  // B[:, c0+w1 : c0+w) -= X[:, c0 : c0+w1) * L[c0+w1 : c0+w, c0 : c0+w1)^T
+  e = gemm_call(h, 0, 0, Bw + (long)c0 * 128, ldw, 0, L + (long)(c0 + w1) * 128 * lda + (long)c0 * 128, lda, 0,
+                Bw + (long)(c0 + w1) * 128, ldw, 0, mp / 128, w2, w1 * 128, 0, 0, -1.0, 1.0, 1);
+  if (e != hipSuccess) return e;
+  return trsm_rec(h, Bw, ldw, mp, c0 + w1, w2);
+}
+
+extern "C" int mi_gp_predict(mi_gp_handle* h, const double* Xnew_dev, int m, double* work_dev, long ldw,
+                             double* mean_dev, double* var_dev, int pred_noise) {
+  if (!h || !Xnew_dev || !work_dev || !mean_dev || !var_dev || m <= 0) return -1;
+  if (!h->factored) { snprintf(h->err, sizeof(h->err), "mi_gp_predict: call mi_gp_factor first"); return -1; }
+  if (ldw < h->np || (ldw & 1)) { snprintf(h->err, sizeof(h->err), "mi_gp_predict: ldw must be even and >= padded n"); return -1; }
+  HCK(hipSetDevice(h->device), "hipSetDevice");
+  const int mp = (m + 127) / 128 * 128;
+  // K(Xnew, X): one prediction point per row, zeros in the padding
+  HCK(launch_assemble(h->spec, h->theta_dev, Xnew_dev, m, h->buf.X_dev, h->n, work_dev, ldw, mp, h->np, 0, 0, h->stream),
+      "assemble cross");
+  HCK(trsm_rec(h, work_dev, ldw, mp, 0, h->ntc), "trsm");
+  // Stationary.diag == 1: the composite diagonal is the +/* fold of kv; pred_noise adds sqrt(gv)^2
+  const int nk = h->spec.nkern, d = h->spec.d;
+  const double* th = h->theta_host;
+  double kd = th[nk * d];
+  for (int c = 1; c < nk; ++c) kd = (h->spec.op[c - 1] == 0) ? kd + th[nk * d + c] : kd * th[nk * d + c];
+  const double sg = std::sqrt(th[nk * d + 2 * nk]);
+  HCK(launch_predict_reduce(work_dev, ldw, h->buf.K_dev + (long)h->np * h->buf.lda, h->n, m, kd,
+                            pred_noise ? sg * sg : 0.0, mean_dev, var_dev, h->stream), "predict_reduce");
+  HCK(hipStreamSynchronize(h->stream), "stream sync");
   return 0;
 }

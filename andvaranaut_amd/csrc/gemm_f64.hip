@@ -108,11 +108,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(GemmParams p) {
   // XCD-aware remap: blocks b, b+8, b+16.. share an XCD (and its L2); give each XCD a contiguous
   // run of tile indices so neighbouring tiles (same A strip, adjacent B strips) hit in that L2.
   const int nblk = gridDim.x;
-  int idx;
-  {
+  int idx = blockIdx.x;
+  if (p.kmode == 0) {
     const int b = blockIdx.x, x = b & 7, q = nblk >> 3, r = nblk & 7;
     idx = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
-  }
+  }  // triangular k-ranges: per-tile work varies with the tile index, keep the round-robin deal balanced
   int ti, tj;
   tile_from_index(p, idx, ti, tj);
   if (p.kmode == 2) ti = p.mt - 1 - ti;  // longest-K tiles (largest ti) first
@@ -121,6 +121,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(GemmParams p) {
   if (p.kmode == 1) kbeg = j0;
   else if (p.kmode == 2) kend = i0 + TILE;
   else if (p.kmode == 3) kbeg = i0;
+  else if (p.kmode == 4) kend = j0 + TILE;
 
   const double* A = p.A + (long)blockIdx.z * p.strideA;
   const double* B = p.B + (long)blockIdx.z * p.strideB;

@@ -1,0 +1,353 @@
+// Kernels around the factorisation for the hyper-parameter gradient and
+// the posterior conditional (K8):
+//   set_identity_blocks : identity into the 128x128 diagonal blocks of U (input of the leaf inverses)
+//   trmv_upper          : alpha = U beta  with U = L^-T upper triangular  (== L^-T L^-1 y, gpmcmc.py:315)
+//   grad_contract       : dLML/dtheta_k = 1/2 sum_ij (alpha_i alpha_j - Kinv_ij) dK_ij/dtheta_k, all
+//                         parameters in one pass over the lower triangle ("assembly shaped": the
+//                         covariance and its derivatives are recomputed from X, only Kinv is read)
+//   predict_reduce      : mu_i = A_i . beta,  var_i = kdiag - |A_i|^2 (+ gv)   (gpmcmc.py:766-778)
+// The reference obtains the gradient by reverse-mode autodiff through the PyTensor graph inside
+// pm.find_MAP / pm.sample (gpmcmc.py:345,351); the analytic form is restated in oracle/gp_oracle.py.
+#include "migp_kernels.h"
+
+namespace migp {
+
+constexpr int GT = 64;  // contraction tile
+constexpr int GDCH = 32;
+constexpr int GDLD = GDCH + 1;
+
+__global__ void set_identity_blocks_kernel(double* __restrict__ U, long ld) {
+  double* blk = U + (long)blockIdx.x * 128 * ld + (long)blockIdx.x * 128;
+  for (int e = threadIdx.x; e < 128 * 128; e += blockDim.x) {
+    const int r = e >> 7, c = e & 127;
+    blk[(long)r * ld + c] = (r == c) ? 1.0 : 0.0;
+  }
+}
+
+// alpha[i] = sum_{k >= i} U[i][k] * beta[k], one wave per row, rows [0, n); U is np x ld, columns
+// beyond n hold the padding (identity diagonal / zeros) and beta is zero there by construction.
+__global__ __launch_bounds__(256) void trmv_upper_kernel(const double* __restrict__ U, long ld,
+                                                         const double* __restrict__ beta, int n,
+                                                         double* __restrict__ alpha) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= n) return;
+  const double* u = U + (long)row * ld;
+  double s = 0.0;
+  const int k0 = row & ~63;
+  for (int k = k0 + lane; k < n; k += 64) {
+    if (k >= row) s += u[k] * beta[k];
+  }
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if (lane == 0) alpha[row] = s;
+}
+
+// d k / d r2 of the base kernels (matches oracle base_kernel_dr2) and the value itself
+__device__ __forceinline__ void base_kernel_val_der(int kid, double r2, double alpha, double& k, double& dk,
+                                                    double& dalpha) {
+  dalpha = 0.0;
+  if (kid == KID_RBF) {
+    k = exp(-0.5 * r2);
+    dk = -0.5 * k;
+  } else if (kid == KID_RATQUAD) {
+    const double u = 0.5 * r2 / alpha;
+    k = pow(1.0 + u, -alpha);
+    dk = -0.5 * k / (1.0 + u);
+    dalpha = k * (-log1p(u) + u / (1.0 + u));
+  } else {
+    const double r = sqrt(r2 + 1e-12);
+    if (kid == KID_MATERN52) {
+      const double e = exp(-2.23606797749979 * r);
+      k = (1.0 + 2.23606797749979 * r + 5.0 / 3.0 * (r * r)) * e;
+      dk = -(5.0 / 6.0) * (1.0 + 2.23606797749979 * r) * e;
+    } else if (kid == KID_MATERN32) {
+      const double e = exp(-1.7320508075688772 * r);
+      k = (1.0 + 1.7320508075688772 * r) * e;
+      dk = -1.5 * e;
+    } else {
+      k = exp(-0.5 * r);
+      dk = -0.25 * k / r;
+    }
+  }
+}
+
+// One 64x64 tile of the lower triangle per workgroup; thread (ty, tx) owns the 4x4 strided
+// micro-tile rows ty+16a, cols tx+16b.  part[blockIdx.x][p] receives the block's partial sums.
+// Parameter order p: ls(nk*d), kv(nk), alpha(nk), gv, jitter.
+template <int NK>
+__global__ __launch_bounds__(256) void grad_contract_kernel(KernSpec spec, const double* __restrict__ theta,
+                                                            const double* __restrict__ X, int n,
+                                                            const double* __restrict__ W, long ldw,
+                                                            const double* __restrict__ alpha_v,
+                                                            double* __restrict__ part) {
+  __shared__ double Xi[GT * GDLD];
+  __shared__ double Xj[GT * GDLD];
+  __shared__ double red[256];
+  const int tid = threadIdx.x;
+  int ti, tj;
+  {
+    const int e = blockIdx.x;
+    int t = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
+    while ((t + 1) * (t + 2) / 2 <= e) ++t;
+    while (t * (t + 1) / 2 > e) --t;
+    ti = t;
+    tj = e - t * (t + 1) / 2;
+  }
+  const int i0 = ti * GT, j0 = tj * GT;
+  const int tx = tid & 15, ty = tid >> 4;
+  const int d = spec.d;
+  const double* ls = theta;
+  const double* kv = theta + NK * d;
+  const double* al = kv + NK;
+  const int P = NK * d + 2 * NK + 2;
+  double* out = part + (long)blockIdx.x * P;
+
+  // weights: w_ab = (alpha_i alpha_j - W_ij) * (1 below the diagonal, 1/2 on it, 0 above / padding)
+  double wgt[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int gi = i0 + ty + 16 * a, gj = j0 + tx + 16 * b;
+      double w = 0.0;
+      if (gi < n && gj < n && gj <= gi) {
+        w = alpha_v[gi] * alpha_v[gj] - W[(long)gi * ldw + gj];
+        if (gi == gj) w *= 0.5;
+      }
+      wgt[a][b] = w;
+    }
+
+  // pass 1: per-component scaled squared distances r2[c] (direct form) -> value, derivative, fold
+  double kval[NK][4][4], dkv[NK][4][4], dal[NK][4][4];
+#pragma unroll
+  for (int c = 0; c < NK; ++c) {
+    double r2[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) r2[a][b] = 0.0;
+    for (int m0 = 0; m0 < d; m0 += GDCH) {
+      const int dc = min(GDCH, d - m0);
+      __syncthreads();
+      for (int e = tid; e < GT * GDCH; e += 256) {
+        const int r = e / GDCH, m = e % GDCH;
+        double vi = 0.0, vj = 0.0;
+        if (m < dc) {
+          const double il = 1.0 / ls[c * d + m0 + m];
+          if (i0 + r < n) vi = X[(long)(i0 + r) * d + m0 + m] * il;
+          if (j0 + r < n) vj = X[(long)(j0 + r) * d + m0 + m] * il;
+        }
+        Xi[r * GDLD + m] = vi;
+        Xj[r * GDLD + m] = vj;
+      }
+      __syncthreads();
+      for (int m = 0; m < dc; ++m) {
+        double xi[4], xj[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) xi[a] = Xi[(ty + 16 * a) * GDLD + m];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) xj[b] = Xj[(tx + 16 * b) * GDLD + m];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            const double df = xi[a] - xj[b];
+            r2[a][b] += df * df;
+          }
+      }
+    }
+    const int kid = spec.kid[c];
+    const double kvc = kv[c], alc = al[c];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        double k, dk, da;
+        base_kernel_val_der(kid, r2[a][b], alc, k, dk, da);
+        kval[c][a][b] = kvc * k;
+        dkv[c][a][b] = kvc * dk;
+        dal[c][a][b] = kvc * da;
+      }
+  }
+  // coefficient dK/dK_c of the left-to-right fold, times the weight
+  double wc[NK][4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      double pref[NK];
+      double T = kval[0][a][b];
+      pref[0] = 1.0;
+#pragma unroll
+      for (int c = 1; c < NK; ++c) {
+        pref[c] = (spec.op[c - 1] == 0) ? 1.0 : T;
+        T = (spec.op[c - 1] == 0) ? T + kval[c][a][b] : T * kval[c][a][b];
+      }
+#pragma unroll
+      for (int c = 0; c < NK; ++c) {
+        double coef = pref[c];
+#pragma unroll
+        for (int c2 = c + 1; c2 < NK; ++c2)
+          if (spec.op[c2 - 1] == 1) coef *= kval[c2][a][b];
+        wc[c][a][b] = wgt[a][b] * coef;
+      }
+    }
+
+  // block reduction helper
+  auto block_sum = [&](double v) -> double {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+  };
+
+  // kv, alpha, gv, jitter
+#pragma unroll
+  for (int c = 0; c < NK; ++c) {
+    double skv = 0.0, sal = 0.0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        skv += wc[c][a][b] * kval[c][a][b];
+        sal += wc[c][a][b] * dal[c][a][b];
+      }
+    skv = block_sum(skv);
+    sal = block_sum(sal);
+    if (tid == 0) {
+      out[NK * d + c] = skv / kv[c];
+      out[NK * d + NK + c] = sal;
+    }
+  }
+  {
+    double sd = 0.0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        if (i0 + ty + 16 * a == j0 + tx + 16 * b) sd += wgt[a][b];  // already carries the 1/2
+    sd = block_sum(sd);
+    if (tid == 0) {
+      out[NK * d + 2 * NK] = sd;
+      out[NK * d + 2 * NK + 1] = sd;
+    }
+  }
+  // length scales: dK/dl_{c,m} = wc * kv dk/dr2 * (-2/l_m) * ((x_im - x_jm)/l_m)^2
+#pragma unroll
+  for (int c = 0; c < NK; ++c) {
+    for (int m0 = 0; m0 < d; m0 += GDCH) {
+      const int dc = min(GDCH, d - m0);
+      __syncthreads();
+      for (int e = tid; e < GT * GDCH; e += 256) {
+        const int r = e / GDCH, m = e % GDCH;
+        double vi = 0.0, vj = 0.0;
+        if (m < dc) {
+          const double il = 1.0 / ls[c * d + m0 + m];
+          if (i0 + r < n) vi = X[(long)(i0 + r) * d + m0 + m] * il;
+          if (j0 + r < n) vj = X[(long)(j0 + r) * d + m0 + m] * il;
+        }
+        Xi[r * GDLD + m] = vi;
+        Xj[r * GDLD + m] = vj;
+      }
+      __syncthreads();
+      for (int m = 0; m < dc; ++m) {
+        double xi[4], xj[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) xi[a] = Xi[(ty + 16 * a) * GDLD + m];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) xj[b] = Xj[(tx + 16 * b) * GDLD + m];
+        double s = 0.0;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            const double df = xi[a] - xj[b];
+            s += wc[c][a][b] * dkv[c][a][b] * (df * df);
+          }
+        s = block_sum(s);
+        if (tid == 0) out[c * d + m0 + m] = s * (-2.0 / ls[c * d + m0 + m]);
+      }
+    }
+  }
+}
+
+// grad[p] = sum_b part[b][p] in a fixed order (the weights already are 1 below the diagonal and 1/2
+// on it, which is 1/2 sum over the full symmetric matrix).
+__global__ void grad_final_kernel(const double* __restrict__ part, int nblk, int P, double* __restrict__ grad) {
+  const int p = blockIdx.x;
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += 256) s += part[(long)b * P + p];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) grad[p] = red[0];
+}
+
+// mean[i] = A_i . beta ; var[i] = kdiag - |A_i|^2 (+ noise), one wave per prediction point
+__global__ __launch_bounds__(256) void predict_reduce_kernel(const double* __restrict__ A, long lda,
+                                                             const double* __restrict__ beta, int n, int m,
+                                                             double kdiag, double noise, double* __restrict__ mean,
+                                                             double* __restrict__ var) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= m) return;
+  const double* a = A + (long)row * lda;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = lane; k < n; k += 64) {
+    const double v = a[k];
+    s1 += v * beta[k];
+    s2 += v * v;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    s1 += __shfl_down(s1, off, 64);
+    s2 += __shfl_down(s2, off, 64);
+  }
+  if (lane == 0) {
+    mean[row] = s1;
+    var[row] = kdiag - s2 + noise;
+  }
+}
+
+hipError_t launch_set_identity_blocks(double* U, long ld, int nblocks, hipStream_t stream) {
+  set_identity_blocks_kernel<<<nblocks, 256, 0, stream>>>(U, ld);
+  return hipGetLastError();
+}
+
+hipError_t launch_trmv_upper(const double* U, long ld, const double* beta, int n, double* alpha, hipStream_t stream) {
+  trmv_upper_kernel<<<(n + 3) / 4, 256, 0, stream>>>(U, ld, beta, n, alpha);
+  return hipGetLastError();
+}
+
+int grad_contract_blocks(int n) {
+  const int nt = (n + GT - 1) / GT;
+  return nt * (nt + 1) / 2;
+}
+
+hipError_t launch_grad_contract(const KernSpec& spec, const double* theta, const double* X, int n, const double* W,
+                                long ldw, const double* alpha, double* part, double* grad, hipStream_t stream) {
+  const int nblk = grad_contract_blocks(n);
+  const int P = spec.nkern * spec.d + 2 * spec.nkern + 2;
+  switch (spec.nkern) {
+    case 1: grad_contract_kernel<1><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part); break;
+    case 2: grad_contract_kernel<2><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part); break;
+    case 3: grad_contract_kernel<3><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part); break;
+    default: grad_contract_kernel<4><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part); break;
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  grad_final_kernel<<<P, 256, 0, stream>>>(part, nblk, P, grad);
+  return hipGetLastError();
+}
+
+hipError_t launch_predict_reduce(const double* A, long lda, const double* beta, int n, int m, double kdiag,
+                                 double noise, double* mean, double* var, hipStream_t stream) {
+  predict_reduce_kernel<<<(m + 3) / 4, 256, 0, stream>>>(A, lda, beta, n, m, kdiag, noise, mean, var);
+  return hipGetLastError();
+}
+
+}  // namespace migp

@@ -303,7 +303,11 @@ __global__ __launch_bounds__(256, 1) void potrf_leaf128_kernel(double* __restric
 // One wave per 16 rows; tiles kept transposed: T_j[r] = B[row0 + (l&15)][16j + 4r + (l>>4)].
 __global__ __launch_bounds__(256, 1) void trsm_strip128_kernel(const double* __restrict__ Lblk, long lda,
                                                                 const double* __restrict__ dinv,
-                                                                double* __restrict__ B, long ldb) {
+                                                                double* __restrict__ B, long ldb, long strideL,
+                                                                long strideB) {
+  Lblk += (long)blockIdx.y * strideL;
+  dinv += (long)blockIdx.y * 2048;
+  B += (long)blockIdx.y * strideB;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* Ls = smem;  // [128][LEAF_LD] lower triangle of L
   const int tid = threadIdx.x;
@@ -372,7 +376,14 @@ hipError_t launch_potrf_leaf128(double* Ablk, long lda, double* dinv, int col0, 
 hipError_t launch_trsm_strip128(const double* Lblk, long lda, const double* dinv, double* B, long ldb, int m,
                                 hipStream_t stream) {
   if (m <= 0) return hipSuccess;
-  trsm_strip128_kernel<<<m / 64, 256, STRIP_LDS_BYTES, stream>>>(Lblk, lda, dinv, B, ldb);
+  trsm_strip128_kernel<<<m / 64, 256, STRIP_LDS_BYTES, stream>>>(Lblk, lda, dinv, B, ldb, 0, 0);
+  return hipGetLastError();
+}
+
+hipError_t launch_trsm_strip128_batched(const double* Lblk, long lda, long strideL, const double* dinv, double* B,
+                                        long ldb, long strideB, int m, int batch, hipStream_t stream) {
+  if (m <= 0 || batch <= 0) return hipSuccess;
+  trsm_strip128_kernel<<<dim3(m / 64, batch), 256, STRIP_LDS_BYTES, stream>>>(Lblk, lda, dinv, B, ldb, strideL, strideB);
   return hipGetLastError();
 }
 

@@ -15,7 +15,7 @@ struct GemmParams {
   int mt, nt;                      // output tiles (128 x 128) in rows / columns
   int k;                           // contraction length, multiple of 32
   int tri;                         // 1: only tiles with tj <= min(ti, nt-1)  (SYRK / trapezoid)
-  int kmode;                       // 0 full k; 1 k >= tj*128; 2 k < (ti+1)*128; 3 k >= ti*128
+  int kmode;                       // 0 full k; 1 k >= tj*128; 2 k < (ti+1)*128; 3 k >= ti*128; 4 k < (tj+1)*128
   double alpha, beta;
 };
 // opX_kmajor = 0: operand stored [x][k] (A row-major m x k / B stored n x k, i.e. "B^T");
@@ -31,6 +31,9 @@ hipError_t launch_potrf_leaf128(double* Ablk, long lda, double* dinv, int col0, 
 // X * L^T = B in place on the m x 128 panel B (m multiple of 64).
 hipError_t launch_trsm_strip128(const double* Lblk, long lda, const double* dinv, double* B, long ldb, int m,
                                 hipStream_t stream);
+// batched form: leaf b uses Lblk + b*strideL, dinv + b*2048, B + b*strideB (m rows each)
+hipError_t launch_trsm_strip128_batched(const double* Lblk, long lda, long strideL, const double* dinv, double* B,
+                                        long ldb, long strideB, int m, int batch, hipStream_t stream);
 
 // ---------------------------------------------------------------- assemble.hip
 enum { KID_RBF = 0, KID_MATERN52 = 1, KID_MATERN32 = 2, KID_EXPONENTIAL = 3, KID_RATQUAD = 4 };
@@ -48,5 +51,15 @@ hipError_t launch_assemble(const KernSpec& spec, const double* theta, const doub
                            hipStream_t stream);
 hipError_t launch_set_yrows(double* K, long ldk, int row0, int cols_pad, const double* y, int n, hipStream_t stream);
 hipError_t launch_lml_reduce(const double* L, long ld, const double* beta, int n, double* out, hipStream_t stream);
+
+// ---------------------------------------------------------------- grad_predict.hip
+hipError_t launch_set_identity_blocks(double* U, long ld, int nblocks, hipStream_t stream);
+hipError_t launch_trmv_upper(const double* U, long ld, const double* beta, int n, double* alpha, hipStream_t stream);
+int grad_contract_blocks(int n);
+// part: [grad_contract_blocks(n)][ntheta] scratch; grad: [ntheta] (natural parameters, C-ABI order)
+hipError_t launch_grad_contract(const KernSpec& spec, const double* theta, const double* X, int n, const double* W,
+                                long ldw, const double* alpha, double* part, double* grad, hipStream_t stream);
+hipError_t launch_predict_reduce(const double* A, long lda, const double* beta, int n, int m, double kdiag,
+                                 double noise, double* mean, double* var, hipStream_t stream);
 
 }  // namespace migp

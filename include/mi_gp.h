@@ -69,10 +69,28 @@ int mi_gp_lml(mi_gp_handle* h, const double* theta_host, double* lml_out);
 /* sum log L_ii and |L^-1 y|^2 of the last factorisation */
 int mi_gp_lml_parts(mi_gp_handle* h, double* logdet_out, double* quad_out);
 
+/* LML and its gradient w.r.t. the natural parameters, grad_out[mi_gp_num_theta()] in theta order
+ * (d/d jitter equals d/d gv):  dLML/dtheta_k = 1/2 tr((alpha alpha^T - K^-1) dK/dtheta_k), K^-1 = L^-T L^-1
+ * formed on the fp64 MFMA GEMM.  Replaces the dlogp half of model.logp_dlogp_function that
+ * pm.find_MAP (gpmcmc.py:332,345,357) and pm.sample / NUTS (gpmcmc.py:351) call per step. */
+int mi_gp_lml_grad(mi_gp_handle* h, const double* theta_host, double* lml_out, double* grad_out);
+
+/* Factorise K(theta) + jitter I + gv I (the conditional's form, [3P] Marginal._build_conditional) and
+ * keep L and beta = L^-1 y on the device for mi_gp_predict.  Replaces the first half of
+ * gp.predict(x, point=hyps, diag=True, pred_noise=True) at gpmcmc.py:593-594. */
+int mi_gp_factor(mi_gp_handle* h, const double* theta_host);
+/* Posterior mean and diagonal variance at m new points (Xnew_dev m x d, converted inputs):
+ * A = L^-1 K(X, X*), mu = A^T beta, var = kdiag - colsum(A o A) (+ gv if pred_noise); the same algebra
+ * is written out in-tree at gpmcmc.py:766-778.  work_dev is caller scratch of
+ * ceil(m/128)*128 rows x ldw (ldw even, >= mi_gp_padded_n()); mean_dev / var_dev receive m doubles. */
+int mi_gp_predict(mi_gp_handle* h, const double* Xnew_dev, int m, double* work_dev, long ldw, double* mean_dev,
+                  double* var_dev, int pred_noise);
+
 /* profiling: level 0 none, 1 per-phase HIP events, 2 additionally per-GEMM-launch HIP events */
 int mi_gp_set_profiling(mi_gp_handle* h, int level);
-/* out[0..6] = assemble_ms, cholesky_ms, reduce_ms, total_ms, gemm_ms (sum over launches),
- *             gemm_flops (algorithmic), number of gemm launches -- of the last evaluation */
+/* out[0..9] = assemble_ms, cholesky_ms, reduce_ms, total_ms, gemm_ms (sum over launches),
+ *             gemm_flops (algorithmic), number of gemm launches, trtri_ms, lauum_ms, contract_ms
+ *             -- of the last evaluation */
 int mi_gp_timers(mi_gp_handle* h, double* out, int n);
 
 /* ---- block-level operations (also used by the multi-GPU driver and the parity tests) ---- */
@@ -80,7 +98,7 @@ int mi_gp_timers(mi_gp_handle* h, double* out, int n);
 /* C = beta*C + alpha*op(A)*op(B) in fp64 on v_mfma_f64_4x4x4_4b_f64; row-major, m,n multiples of
  * 128, k multiple of 32.  transa=0: A is m x k; 1: A is k x m.  transb=0: B is k x n; 1: B is n x k.
  * tri=1 computes only tiles on/below the block diagonal; kmode restricts k per tile for triangular
- * operands (0 full, 1 k>=col-tile start, 2 k<row-tile end, 3 k>=row-tile start).
+ * operands (0 full, 1 k>=col-tile start, 2 k<row-tile end, 3 k>=row-tile start, 4 k<col-tile end).
  * Replaces the OpenBLAS dgemm/dsyrk calls inside LAPACK dpotrf/dtrtri/dlauum that PyTensor's
  * Cholesky Op reaches (gpmcmc.py:313; scipy.linalg.cholesky). */
 int mi_gp_gemm_f64(int transa, int transb, int m, int n, int k, double alpha, const double* A_dev, long lda,

@@ -1,0 +1,372 @@
+"""GPMCMC: the reference's GP-surrogate facade (andvaranaut/gpmcmc.py:30) with its hot path -- the
+GP log marginal likelihood, its hyper-parameter gradient and the posterior conditional -- running on
+an MI355X through libmi_gp.so instead of PyMC / PyTensor / SciPy-LAPACK.
+
+Same constructor, ``set_data`` / ``sample`` / ``fit`` / ``predict`` / ``change_model`` signatures and the
+same ``hypers`` dictionary keys as the reference (gpmcmc.py:31-32,122,158,175-177,472,522-523;
+keys recorded at tutorial/tutorial.ipynb:529).  Out of scope here: dask-parallel
+target execution, input/output warping inside the posterior (iwgp/cwgp), BO, inverse_opt, plots."""
+import copy
+import os
+import re
+import threading
+from time import time as stopwatch
+
+import numpy as np
+
+from .backend import MiGP, parse_kernel
+from .lhc import latin_sample
+from .nuts import Trace, sample_chain
+from .optimize import find_MAP
+from .priors import HyperModel
+from .transform import _none_conrev
+
+
+class GPMCMC:
+    def __init__(self, xconrevs=None, yconrevs=None, kernel="RBF", noise=True, mean=0, nx=None, ny=None,
+                 priors=None, target=None, parallel=False, nproc=1, constraints=None, rundir=None, verbose=True,
+                 pulse=1, device=0):
+        # argument checks of _core.__init__ (core.py:57-86)
+        if (not isinstance(nx, int)) or (nx < 1):
+            raise Exception("Error: must specify an integer number of input dimensions > 0")
+        if (not isinstance(ny, int)) or (ny < 1):
+            raise Exception("Error: must specify an integer number of output dimensions > 0")
+        if (not isinstance(priors, list)) or (len(priors) != nx):
+            raise Exception("Error: must provide list of scipy.stats univariate priors of length nx")
+        if any(getattr(p, "__module__", None) != "scipy.stats._distn_infrastructure" for p in priors):
+            raise Exception("Error: must provide list of scipy.stats univariate priors of length nx")
+        if not callable(target):
+            raise Exception("Error: must provide target function which produces output from specified inputs")
+        if not isinstance(parallel, bool):
+            raise Exception("Error: parallel must be type bool.")
+        if parallel:
+            raise NotImplementedError("dask-parallel target evaluation (core.py:105-134) is outside this backend")
+        self.nx, self.ny, self.priors, self.target = nx, ny, priors, target
+        self.parallel, self.nproc, self.pulse = parallel, nproc, pulse
+        self.constraints, self.verbose = constraints, verbose
+        self.rundir = "runs" if rundir is None else rundir
+        self.device = int(device)
+        self.nsamp = 0
+        self.x = np.empty((0, nx))
+        self.y = np.empty((0, ny))
+        self.xc = copy.deepcopy(self.x)
+        self.yc = copy.deepcopy(self.y)
+        self.__conrev_check(xconrevs, yconrevs)
+        self.ym = copy.deepcopy(self.y)
+        self.change_model(kernel, noise, mean)
+        self.train = None
+        self.test = None
+
+    # ------------------------------------------------------------------ data plumbing
+    def zero_mean(self, x):
+        return np.zeros(self.ny)
+
+    def __conrev_check(self, xconrevs, yconrevs):
+        """gpmcmc.py:98-119."""
+        xconrevs = [None] * self.nx if xconrevs is None else xconrevs
+        yconrevs = [None] * self.ny if yconrevs is None else yconrevs
+        if not isinstance(xconrevs, list) or len(xconrevs) != self.nx:
+            raise Exception("Error: xconrevs must be None or list of conversion/reversion classes of size nx")
+        if not isinstance(yconrevs, list) or len(yconrevs) != self.ny:
+            raise Exception("Error: yconrevs must be None or list of conversion/reversion classes of size ny")
+        for lst in (xconrevs, yconrevs):
+            for j, c in enumerate(lst):
+                if c is None:
+                    lst[j] = _none_conrev()
+                elif (not callable(c.con)) or (not callable(c.rev)):
+                    raise Exception("Error: Provided data conversion/reversion function not callable.")
+        self.xconrevs, self.yconrevs = xconrevs, yconrevs
+
+    def __evaluate(self, xsamps, fun):
+        """Serial branch of _core.__vector_solver (core.py:137-215): failed / non-finite rows are dropped."""
+        keep_x, ys = [], []
+        for i in range(len(xsamps)):
+            try:
+                yout = np.atleast_1d(np.asarray(fun(xsamps[i, :]), dtype=np.float64))
+            except Exception as e:
+                print(f"Warning: Target function evaluation failed at sample {i} with x values: {xsamps[i, :]}; "
+                      f"error message: {e}")
+                continue
+            if yout.shape != (self.ny,):
+                raise Exception("Error: number of target function outputs is not equal to ny")
+            if np.any(np.isnan(yout)) or np.any(np.abs(yout) == np.inf):
+                print(f"Warning: Target function evaluation returned inf/nan at sample with x values: {xsamps[i, :]}")
+                continue
+            keep_x.append(xsamps[i, :])
+            ys.append(yout)
+        if not ys:
+            return np.empty((0, self.nx)), np.empty((0, self.ny))
+        return np.array(keep_x), np.array(ys)
+
+    def __reconvert(self):
+        self.xc = np.empty_like(self.x)
+        self.yc = np.empty_like(self.y)
+        for i in range(self.nx):
+            self.xc[:, i] = self.xconrevs[i].con(self.x[:, i])
+        for i in range(self.ny):
+            self.yc[:, i] = self.yconrevs[i].con(self.y[:, i] - self.ym[:, i])
+
+    def __mean_eval(self):
+        xm, ym = self.__evaluate(self.x, self.mean)
+        if len(xm) != len(self.x):
+            raise Exception("Mean function not valid at every x point in dataset")
+        self.ym = ym.reshape(len(self.x), self.ny)
+
+    def sample(self, nsamps, seed=None):
+        """gpmcmc.py:158-172 + lhc.py:24-37."""
+        if not isinstance(nsamps, int) or (nsamps < 1):
+            raise Exception("Error: nsamps argument must be an integer > 0")
+        if self.verbose:
+            print(f"Evaluating {nsamps} latin hypercube samples...")
+        xs = latin_sample(self.priors, nsamps, seed)
+        xs, ys = self.__evaluate(xs, self.target)
+        self.x = np.r_[self.x, xs]
+        self.y = np.r_[self.y, ys]
+        self.nsamp = len(self.x)
+        self.__mean_eval()
+        self.__reconvert()
+        self.train = self.test = None
+
+    def set_data(self, x, y):
+        """gpmcmc.py:122-137 + lhc.py:113-131."""
+        if not isinstance(x, np.ndarray) or len(x.shape) != 2 or x.dtype != "float64" or x.shape[1] != self.nx:
+            raise Exception("Error: Setting data requires a 2d numpy array of float64 inputs")
+        if not isinstance(y, np.ndarray) or len(y.shape) != 2 or y.dtype != "float64" or y.shape[1] != self.ny:
+            raise Exception("Error: Setting data requires a 2d numpy array of float64 outputs")
+        for i in range(self.nx):
+            intv = self.priors[i].interval(1.0)
+            if not all(x[:, i] >= intv[0]) or not all(x[:, i] <= intv[1]):
+                raise Exception("Error: provided x data must fit within provided input distribution ranges.")
+        self.x, self.y, self.nsamp = x, y, len(x)
+        self.__mean_eval()
+        self.__reconvert()
+        self.train = self.test = None
+
+    def change_conrevs(self, xconrevs=None, yconrevs=None):
+        self.__conrev_check(xconrevs, yconrevs)
+        self.__reconvert()
+
+    def change_xconrevs(self, xconrevs=None):
+        self.__conrev_check(xconrevs, self.yconrevs)
+        self.__reconvert()
+
+    def change_yconrevs(self, yconrevs=None):
+        self.__conrev_check(self.xconrevs, yconrevs)
+        self.__reconvert()
+
+    def train_test(self, training_frac=0.9):
+        from sklearn.model_selection import train_test_split
+
+        self.nsamp = len(self.x)
+        self.train, self.test = train_test_split(np.arange(self.nsamp), train_size=training_frac)
+
+    def change_model(self, kernel=None, noise=None, mean=None):
+        """gpmcmc.py:472-519: kernel string grammar, noise flag, mean function; scrubs the fitted model."""
+        kernel = self.kernel if kernel is None else kernel
+        noise = self.noise if noise is None else noise
+        if mean is not None:
+            self.mean = self.zero_mean if (not callable(mean) and mean == 0) else mean
+            if len(self.x) > 0:
+                self.__mean_eval()
+                self.__reconvert()
+        kerns, ops = parse_kernel(kernel)
+        if not isinstance(noise, bool):
+            raise Exception("Error: noise must be of type bool")
+        self.kernel, self.kerns, self.ops, self.nkern, self.noise = kernel, kerns, ops, len(kerns), noise
+        self.__release()
+        self.m = None
+        self.hypers = None
+
+    def __release(self):
+        gp = getattr(self, "gp", None)
+        if gp is not None:
+            gp.close()
+        self.gp = None
+
+    # ------------------------------------------------------------------ fit
+    def fit(self, method="map", return_data=False, iwgp=False, cwgp=False, jitter=1e-6, truncate=False,
+            restarts=1, **kwargs):
+        """gpmcmc.py:175-182."""
+        self.m, self.gp, self.hypers, data = self.__fit(self.x, self.y - self.ym, method, iwgp, cwgp, jitter,
+                                                        truncate, restarts, **kwargs)
+        if return_data:
+            return data
+
+    def _converted(self, x, y):
+        xin = np.zeros_like(x)
+        for i in range(self.nx):
+            xin[:, i] = self.xconrevs[i].con(x[:, i])
+        yin = self.yconrevs[0].con(y[:, 0])  # only y[:,0] is modelled (gpmcmc.py:279)
+        return np.ascontiguousarray(xin), np.ascontiguousarray(yin)
+
+    def __fit(self, x, y, method, iwgp, cwgp, jitter=1e-6, truncate=False, restarts=1, **kwargs):
+        if iwgp or cwgp:
+            raise NotImplementedError("input/output warping inside the posterior (gpmcmc.py:211-279) is not "
+                                      "part of this backend yet")
+        model = HyperModel(self.nx, self.kerns, noise=self.noise, truncate=truncate, jitter=jitter)
+        xin, yin = self._converted(x, y)
+        self.__release()
+        gp = MiGP(xin, yin, self.kernel, device=self.device)
+        fun = lambda q: model.logp_dlogp(q, gp.lml_grad)  # noqa: E731
+        data = None
+        if method == "map":
+            best, mp = -np.inf, None
+            for _ in range(max(int(restarts), 1)):
+                # the reference builds a random start and never passes it (gpmcmc.py:330-332): every
+                # restart begins at the model's initial point, so they coincide; kept as is
+                try:
+                    q, info = find_MAP(fun, model.initial_point(), progressbar=kwargs.get("progressbar", False),
+                                       maxeval=kwargs.get("maxeval", 5000))
+                except Exception:
+                    print("Restart failed")
+                    continue
+                if info["logp"] > best:
+                    best, mp, data = info["logp"], model.point_dict(q), info
+            if mp is None:
+                raise RuntimeError("find_MAP failed")
+            if self.verbose:
+                print(f"MAP: {data['nfev']} evaluations, logp = {data['logp']:,.5g}")
+        elif method == "none":
+            mp = self.hypers
+        elif method in ("mcmc_mean", "mcmc_map"):
+            data = self.__sample(model, gp, xin, yin, **kwargs)
+            if method == "mcmc_mean":
+                mp = self.mean_extract(data)
+            else:
+                mp = self.map_extract(data)
+                try:
+                    q, _ = find_MAP(fun, model.q_from_point(mp))
+                    mp = model.point_dict(q)
+                except Exception:
+                    pass
+        else:
+            raise Exception("method must be one of map, mcmc_map, or mcmc_mean")
+        return model, gp, mp, data
+
+    def __sample(self, model, gp, xin, yin, draws=1000, tune=1000, chains=None, cores=None, target_accept=0.8,
+                 random_seed=None, max_treedepth=10, progressbar=False, devices=None, **_):
+        """pm.sample(**kwargs) of gpmcmc.py:351: independent NUTS chains, one device handle per chain
+        (one chain per GPU when several are visible: SURVEY.md section 8e)."""
+        import torch
+
+        chains = max(2, min(4, os.cpu_count() or 2)) if chains is None else int(chains)
+        ndev = torch.cuda.device_count()
+        devices = list(devices) if devices is not None else [(self.device + i) % max(ndev, 1) for i in range(chains)]
+        seeds = np.random.SeedSequence(random_seed).spawn(chains)
+        results = [None] * chains
+        handles = {self.device: gp}
+
+        by_dev = {}
+        for c in range(chains):
+            by_dev.setdefault(devices[c % len(devices)], []).append(c)
+        # chains that share a device run back to back on one handle; devices run concurrently
+        def run_dev(dev, cs):
+            h = handles.get(dev) or MiGP(xin, yin, self.kernel, device=dev)
+            f = lambda q: model.logp_dlogp(q, h.lml_grad)  # noqa: E731
+            for c in cs:
+                results[c] = sample_chain(f, model.initial_point(), draws=draws, tune=tune,
+                                          target_accept=target_accept, max_treedepth=max_treedepth, seed=seeds[c],
+                                          progressbar=progressbar and c == 0)
+            if dev not in handles:
+                h.close()
+
+        threads = [threading.Thread(target=run_dev, args=(dev, cs)) for dev, cs in by_dev.items()]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if any(r is None for r in results):
+            raise RuntimeError("a NUTS chain failed")
+        posterior = {}
+        qs = np.stack([r["q"] for r in results])  # [chain, draw, nq]
+        for c in range(chains):
+            for k in range(qs.shape[1]):
+                pt = model.point_dict(qs[c, k])
+                for name, val in pt.items():
+                    if name not in posterior:
+                        posterior[name] = np.empty((chains, qs.shape[1]) + np.shape(val))
+                    posterior[name][c, k] = val
+        stats = {"lp": np.stack([r["lp"] for r in results]),
+                 "step_size": np.array([r["step_size"] for r in results]),
+                 "n_leapfrog": np.array([r["n_leapfrog"] for r in results]),
+                 "diverging": np.array([r["diverging"] for r in results])}
+        return Trace(posterior, stats)
+
+    def mean_extract(self, data):
+        """Posterior means over chains and draws (gpmcmc.py:404-412)."""
+        return {k: np.array(v.mean(axis=(0, 1))) for k, v in data.posterior.items()}
+
+    def map_extract(self, data):
+        """Draw with the largest log-posterior (gpmcmc.py:415-430)."""
+        lp = data.sample_stats["lp"].reshape(-1)
+        k = int(np.argmax(lp))
+        if self.verbose:
+            print(f"Max log posterior: {lp[k]}")
+        mp = {}
+        for name, v in data.posterior.items():
+            flat = v.reshape((-1,) + v.shape[2:])
+            mp[name] = np.array(flat[k])
+        return mp
+
+    # ------------------------------------------------------------------ predict
+    def _theta_from_hypers(self, hyps, jitter):
+        model = self.m
+        vals = {"l": np.atleast_1d(hyps["l"]), "kv": np.atleast_1d(hyps["kv"])}
+        if self.noise:
+            vals["gv"] = np.atleast_1d(hyps["gv"])
+        if "alpha" in hyps:
+            vals["alpha"] = np.atleast_1d(hyps["alpha"])
+        th = model.theta(vals)
+        th[-1] = jitter
+        return th
+
+    def predict(self, x, return_var=False, convert=True, revert=True, normvar=False, jitter=1e-6, EI=False,
+                EIopt=None, deg=8):
+        """gpmcmc.py:522-542."""
+        if self.gp is None or self.hypers is None:
+            raise Exception("Error: fit the GP before predicting")
+        if convert:
+            xarg = np.zeros_like(x)
+            for i in range(self.nx):
+                xarg[:, i] = self.xconrevs[i].con(x[:, i])
+        else:
+            xarg = copy.deepcopy(x)
+            x = copy.deepcopy(x)
+            for i in range(self.nx):
+                x[:, i] = self.xconrevs[i].rev(x[:, i])
+        if self.verbose:
+            print("Predicting...")
+        t0 = stopwatch()
+        mu, var = self.gp.predict(self._theta_from_hypers(self.hypers, jitter), xarg, pred_noise=True)
+        if self.verbose:
+            print(f"Time taken: {stopwatch() - t0:0.2f} s")
+        y, yv = mu.reshape((-1, 1)), var.reshape((-1, 1))
+        if revert:
+            y, yv = self.__gh_stats(x, y, yv, normvar, deg, EI=EI, EIopt=EIopt)
+        return (y, yv) if return_var else y
+
+    def __gh_stats(self, x, y, yv, normvar=True, deg=8, EI=False, EIopt=None):
+        """Gauss-Hermite mean / variance (or EI) of the reverted variable (gpmcmc.py:545-569),
+        vectorised over the prediction points instead of the reference's per-point Python loop."""
+        xi, wi = np.polynomial.hermite.hermgauss(deg)
+        yi = np.sqrt(2.0 * yv) * xi[None, :] + y  # [M, deg]
+        means = np.array([self.mean(x[i, :])[0] for i in range(len(x))]) if self.mean != self.zero_mean else 0.0
+        yir = self.yconrevs[0].rev(yi) + np.reshape(means, (-1, 1) if np.ndim(means) else ())
+        if EI:
+            ydiff = (yir - self.yopt) if EIopt == "max" else (self.yopt - yir)
+            first = np.where(ydiff > 0.0, ydiff, 0.0)
+        else:
+            first = yir
+        ymean = (first @ wi) / np.sqrt(np.pi)
+        ym2 = ((yir ** 2) @ wi) / np.sqrt(np.pi)
+        yout = ymean.reshape((-1, 1))
+        yvout = (ym2 - ymean ** 2).reshape((-1, 1))
+        if normvar:
+            yvout = yvout / np.power(yout, 2)
+        return yout, yvout
+
+    def __del__(self):
+        try:
+            self.__release()
+        except Exception:
+            pass

@@ -66,6 +66,7 @@ def load():
     lib.mi_gp_lml_grad.argtypes = [vp, dp, dp, dp]
     lib.mi_gp_factor.argtypes = [vp, dp]
     lib.mi_gp_predict.argtypes = [vp, vp, ci, vp, cl, vp, vp, ci]
+    lib.mi_gp_set_option.argtypes = [vp, ci, ci]
     lib.mi_gp_set_profiling.argtypes = [vp, ci]
     lib.mi_gp_timers.argtypes = [vp, dp, ci]
     lib.mi_gp_gemm_f64.argtypes = [ci, ci, ci, ci, ci, cd, vp, cl, vp, cl, cd, vp, cl, ci, ci, ci, cl, cl, cl, vp]
@@ -90,6 +91,7 @@ EXPORTS = [
     "mi_gp_lml_grad",
     "mi_gp_factor",
     "mi_gp_predict",
+    "mi_gp_set_option",
     "mi_gp_set_profiling",
     "mi_gp_timers",
     "mi_gp_gemm_f64",

@@ -150,6 +150,10 @@ class MiGP:
                 var[s : s + mc] = var_t.cpu().numpy()
         return mean, var
 
+    def set_option(self, what, value):
+        """0: look-ahead on/off, 1: GEMM variant, 2: super-panel width (tiles)."""
+        self.lib.mi_gp_set_option(self.h, int(what), int(value))
+
     def set_profiling(self, level):
         self.lib.mi_gp_set_profiling(self.h, int(level))
 

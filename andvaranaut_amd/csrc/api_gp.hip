@@ -16,7 +16,10 @@ struct mi_gp_handle {
   int n, np, ntc;       // points, padded points, 128-column tiles
   int ntheta;
   int device;
-  hipStream_t stream;
+  hipStream_t stream;    // trailing updates, assembly, reductions
+  hipStream_t pstream;   // look-ahead panel factorisation (higher priority)
+  hipEvent_t ev_panel, ev_upd;
+  int lookahead;
   mi_gp_buffers buf;
   bool have_data;
   // handle-owned small scratch
@@ -81,6 +84,14 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   h->gemm_ev_used = 0;
   hipError_t e = hipSetDevice(h->device);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) {
+    int lo = 0, hi = 0;
+    hipDeviceGetStreamPriorityRange(&lo, &hi);
+    e = hipStreamCreateWithPriority(&h->pstream, hipStreamNonBlocking, hi);
+  }
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_panel, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_upd, hipEventDisableTiming);
+  h->lookahead = 1;
   if (e == hipSuccess) e = hipMalloc(&h->theta_dev, sizeof(double) * h->ntheta);
   if (e == hipSuccess) e = hipMalloc(&h->out_dev, sizeof(double) * 16);
   if (e == hipSuccess) e = hipMalloc(&h->dinv_dev, sizeof(double) * 2048 * (size_t)h->ntc);
@@ -114,6 +125,8 @@ extern "C" int mi_gp_destroy(mi_gp_handle* h) {
   hipHostFree(h->out_host); hipHostFree(h->info_host); hipHostFree(h->theta_host);
   for (int i = 0; i < 8; ++i) hipEventDestroy(h->ev[i]);
   for (auto& ev : h->gemm_ev) hipEventDestroy(ev);
+  hipEventDestroy(h->ev_panel); hipEventDestroy(h->ev_upd);
+  hipStreamDestroy(h->pstream);
   hipStreamDestroy(h->stream);
   delete h;
   return 0;
@@ -134,6 +147,17 @@ extern "C" int mi_gp_set_data(mi_gp_handle* h, const mi_gp_buffers* b) {
   return 0;
 }
 
+// tuning knobs: what = 0 look-ahead on/off (per handle), 1 GEMM kernel variant (process-wide),
+// 2 super-panel width in 128-column tiles
+extern "C" int mi_gp_set_option(mi_gp_handle* h, int what, int value) {
+  if (!h) return -1;
+  if (what == 0) h->lookahead = value ? 1 : 0;
+  else if (what == 1) set_gemm_variant(value);
+  else if (what == 2) h->cfg.panel_tiles = value;
+  else return -1;
+  return 0;
+}
+
 extern "C" int mi_gp_set_profiling(mi_gp_handle* h, int level) {
   if (!h) return -1;
   h->prof_level = level;
@@ -141,7 +165,8 @@ extern "C" int mi_gp_set_profiling(mi_gp_handle* h, int level) {
 }
 
 // ---------------------------------------------------------------- driver pieces
-static hipError_t prof_gemm(mi_gp_handle* h, const GemmParams& p, int ak, int bk, int batch, double flops) {
+static hipError_t prof_gemm(mi_gp_handle* h, const GemmParams& p, int ak, int bk, int batch, double flops,
+                            hipStream_t st) {
   if (h->prof_level >= 2) {
     if (h->gemm_ev_used + 2 > h->gemm_ev.size()) {
       for (int i = 0; i < 64; ++i) {
@@ -151,18 +176,19 @@ static hipError_t prof_gemm(mi_gp_handle* h, const GemmParams& p, int ak, int bk
         h->gemm_ev.push_back(e);
       }
     }
-    hipEventRecord(h->gemm_ev[h->gemm_ev_used], h->stream);
-    hipError_t r = launch_gemm_f64(p, ak, bk, batch, h->stream);
-    hipEventRecord(h->gemm_ev[h->gemm_ev_used + 1], h->stream);
+    hipEventRecord(h->gemm_ev[h->gemm_ev_used], st);
+    hipError_t r = launch_gemm_f64(p, ak, bk, batch, st);
+    hipEventRecord(h->gemm_ev[h->gemm_ev_used + 1], st);
     h->gemm_ev_used += 2;
     h->gemm_flops_acc += flops;
     return r;
   }
-  return launch_gemm_f64(p, ak, bk, batch, h->stream);
+  return launch_gemm_f64(p, ak, bk, batch, st);
 }
 
 // trapezoid update  A[r0:, c0:c0+nc] -= P P_c^T  with P = A[r0:, k0:k0+kw] (tile units)
-static hipError_t syrk_trapezoid(mi_gp_handle* h, double* A, long lda, int ntr, int r0, int nc, int k0, int kw) {
+static hipError_t syrk_trapezoid(mi_gp_handle* h, double* A, long lda, int ntr, int r0, int nc, int k0, int kw,
+                                 hipStream_t st) {
   GemmParams p;
   p.A = A + (long)r0 * 128 * lda + (long)k0 * 128;
   p.B = p.A;
@@ -181,39 +207,61 @@ static hipError_t syrk_trapezoid(mi_gp_handle* h, double* A, long lda, int ntr, 
   // (full diagonal tiles, a 128-row tile for the y row).
   const double c = nc * 128.0, rows_real = (p.mt - 1) * 128.0;
   const double flops = (double)p.k * (c * (c + 1.0) + 2.0 * (rows_real - c) * c + 2.0 * c);
-  return prof_gemm(h, p, 0, 0, 1, flops);
+  return prof_gemm(h, p, 0, 0, 1, flops, st);
 }
 
 // factor tile columns [c0, c0+w) of the (ntr x ntc)-tile trapezoid, recursively halving w
-static hipError_t chol_panel(mi_gp_handle* h, double* A, long lda, int ntr, int c0, int w) {
+static hipError_t chol_panel(mi_gp_handle* h, double* A, long lda, int ntr, int c0, int w, hipStream_t st) {
   hipError_t e;
   if (w == 1) {
     double* blk = A + (long)c0 * 128 * lda + (long)c0 * 128;
     double* dinv = h->dinv_dev + (size_t)c0 * 2048;
-    e = launch_potrf_leaf128(blk, lda, dinv, c0 * 128, h->info_dev, h->stream);
+    e = launch_potrf_leaf128(blk, lda, dinv, c0 * 128, h->info_dev, st);
     if (e != hipSuccess) return e;
     const int m = (ntr - c0 - 1) * 128;
-    return launch_trsm_strip128(blk, lda, dinv, blk + 128 * lda, lda, m, h->stream);
+    return launch_trsm_strip128(blk, lda, dinv, blk + 128 * lda, lda, m, st);
   }
   const int w1 = w / 2, w2 = w - w1;
-  e = chol_panel(h, A, lda, ntr, c0, w1);
+  e = chol_panel(h, A, lda, ntr, c0, w1, st);
   if (e != hipSuccess) return e;
-  e = syrk_trapezoid(h, A, lda, ntr, c0 + w1, w2, c0, w1);
+  e = syrk_trapezoid(h, A, lda, ntr, c0 + w1, w2, c0, w1, st);
   if (e != hipSuccess) return e;
-  return chol_panel(h, A, lda, ntr, c0 + w1, w2);
+  return chol_panel(h, A, lda, ntr, c0 + w1, w2, st);
 }
 
+// Right-looking blocked Cholesky of the (ntr x ntc)-tile lower trapezoid with one super-panel of
+// look-ahead: while the trailing update of super-panel J runs on the main stream, the next
+// super-panel (whose columns were updated first) is factored on the high-priority panel stream.
 static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int ntc) {
-  int W = h->cfg.panel_tiles > 0 ? h->cfg.panel_tiles : 4;
+  const int W = h->cfg.panel_tiles > 0 ? h->cfg.panel_tiles : 4;
+  hipStream_t T = h->stream, P = h->lookahead ? h->pstream : h->stream;
+  hipError_t e;
+#define CKE(x) do { e = (x); if (e != hipSuccess) return e; } while (0)
+  if (P != T) {  // panel stream starts after everything already queued on the main stream (assembly)
+    CKE(hipEventRecord(h->ev_upd, T));
+    CKE(hipStreamWaitEvent(P, h->ev_upd, 0));
+  }
+  CKE(chol_panel(h, A, lda, ntr, 0, ntc < W ? ntc : W, P));
   for (int J = 0; J < ntc; J += W) {
     const int w = (ntc - J < W) ? (ntc - J) : W;
-    hipError_t e = chol_panel(h, A, lda, ntr, J, w);
-    if (e != hipSuccess) return e;
-    if (J + w < ntc) {
-      e = syrk_trapezoid(h, A, lda, ntr, J + w, ntc - J - w, J, w);
-      if (e != hipSuccess) return e;
+    const int n1 = J + w;  // first tile column right of this super-panel
+    if (P != T) {
+      CKE(hipEventRecord(h->ev_panel, P));
+      CKE(hipStreamWaitEvent(T, h->ev_panel, 0));
     }
+    if (n1 >= ntc) break;
+    const int wn = (ntc - n1 < W) ? (ntc - n1) : W;
+    // (a) bring the next super-panel's columns up to date, then hand them to the panel stream
+    CKE(syrk_trapezoid(h, A, lda, ntr, n1, wn, J, w, T));
+    if (P != T) {
+      CKE(hipEventRecord(h->ev_upd, T));
+      CKE(hipStreamWaitEvent(P, h->ev_upd, 0));
+    }
+    CKE(chol_panel(h, A, lda, ntr, n1, wn, P));
+    // (b) the rest of the trailing matrix, concurrently with that panel factorisation
+    if (n1 + wn < ntc) CKE(syrk_trapezoid(h, A, lda, ntr, n1 + wn, ntc - n1 - wn, J, w, T));
   }
+#undef CKE
   return hipSuccess;
 }
 

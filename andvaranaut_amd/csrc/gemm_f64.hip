@@ -19,6 +19,7 @@
 // This kernel serves: K3 Cholesky trailing / panel updates (NT, lower),
 // K7 triangular inverse levels (NN with triangular k-ranges) and L^-T L^-1 (TN), K8 predict
 // triangular-solve updates (NT).
+#include <cstdlib>
 #include "migp_kernels.h"
 
 namespace migp {
@@ -239,14 +240,202 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(GemmParams p) {
       }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Variant B: 256-thread workgroups (4 waves as 2x2, 64x64 per wave = 4x4 MFMA tiles, 64 accumulator
+// doubles per lane), K chunks of 16, 72 KiB of LDS -> TWO workgroups per CU whose barriers, prologues
+// and C read-modify-write epilogues overlap each other's MFMA loops.
+namespace vb {
+constexpr int BKB = 16;
+constexpr int OPER_B = BKB * LDS_LD;
+constexpr int NT_B = 256;
+constexpr int NQB = TILE * BKB / 2 / NT_B;  // 4
+
+template <bool KMAJOR>
+__device__ __forceinline__ void chunk_offsets(long ld, int tid, unsigned& goff, unsigned& loff, long& gstride) {
+  if (KMAJOR) {
+    const int k = tid >> 6, xc = tid & 63;  // k = 4q + (t>>6)
+    goff = (unsigned)((k * ld + 2 * xc) * 8);
+    loff = (unsigned)((k * LDS_LD + 2 * xc) * 8);
+    gstride = 4 * ld * 8;
+  } else {
+    const int xl = tid & 15, kc = (tid >> 4) & 7, xh = tid >> 7;  // x = 32q + 16*(t>>7) + (t&15)
+    goff = (unsigned)(((xh * 16 + xl) * ld + 2 * kc) * 8);
+    loff = (unsigned)(((2 * kc) * LDS_LD + xh * 16 + xl) * 8);
+    gstride = 32 * ld * 8;
+  }
+}
+__device__ __forceinline__ void chunk_load(const char* __restrict__ base, unsigned goff, long gstride,
+                                           double2_t (&r)[NQB]) {
+#pragma unroll
+  for (int q = 0; q < NQB; ++q) r[q] = *reinterpret_cast<const double2_t*>(base + q * gstride + goff);
+}
+template <bool KMAJOR>
+__device__ __forceinline__ void chunk_store(char* __restrict__ lds, unsigned loff, const double2_t (&r)[NQB]) {
+#pragma unroll
+  for (int q = 0; q < NQB; ++q) {
+    if (KMAJOR) {
+      *reinterpret_cast<double2_t*>(lds + loff + q * (4 * LDS_LD * 8)) = r[q];
+    } else {
+      *reinterpret_cast<double*>(lds + loff + q * (32 * 8)) = r[q].x;
+      *reinterpret_cast<double*>(lds + loff + q * (32 * 8) + LDS_LD * 8) = r[q].y;
+    }
+  }
+}
+}  // namespace vb
+
+template <bool A_KMAJOR, bool B_KMAJOR>
+__global__ __launch_bounds__(vb::NT_B, 2) void gemm_f64_kernel_b(GemmParams p) {
+  using vb::BKB; using vb::OPER_B; using vb::NQB;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* As = smem;               // [2][BKB][LDS_LD]
+  double* Bs = smem + 2 * OPER_B;  // [2][BKB][LDS_LD]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+
+  const int nblk = gridDim.x;
+  int idx = blockIdx.x;
+  if (p.kmode == 0) {
+    const int b = blockIdx.x, x = b & 7, q = nblk >> 3, r = nblk & 7;
+    idx = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+  }
+  int ti, tj;
+  tile_from_index(p, idx, ti, tj);
+  if (p.kmode == 2) ti = p.mt - 1 - ti;
+  const int i0 = ti * TILE, j0 = tj * TILE;
+  int kbeg = 0, kend = p.k;
+  if (p.kmode == 1) kbeg = j0;
+  else if (p.kmode == 2) kend = i0 + TILE;
+  else if (p.kmode == 3) kbeg = i0;
+  else if (p.kmode == 4) kend = j0 + TILE;
+
+  const double* A = p.A + (long)blockIdx.z * p.strideA;
+  const double* B = p.B + (long)blockIdx.z * p.strideB;
+  double* C = p.C + (long)blockIdx.z * p.strideC;
+
+  double4_t acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+  const int nchunk = (kend - kbeg) / BKB;
+  unsigned gA, lA, gB, lB;
+  long sA, sB;
+  vb::chunk_offsets<A_KMAJOR>(p.lda, tid, gA, lA, sA);
+  vb::chunk_offsets<B_KMAJOR>(p.ldb, tid, gB, lB, sB);
+  const char* Ag = reinterpret_cast<const char*>(A_KMAJOR ? A + (long)kbeg * p.lda + i0 : A + (long)i0 * p.lda + kbeg);
+  const char* Bg = reinterpret_cast<const char*>(B_KMAJOR ? B + (long)kbeg * p.ldb + j0 : B + (long)j0 * p.ldb + kbeg);
+  const long stepA = (A_KMAJOR ? (long)BKB * p.lda : (long)BKB) * 8;
+  const long stepB = (B_KMAJOR ? (long)BKB * p.ldb : (long)BKB) * 8;
+  char* Asb = reinterpret_cast<char*>(As);
+  char* Bsb = reinterpret_cast<char*>(Bs);
+  double2_t ra[NQB], rb[NQB];
+  if (nchunk > 0) {
+    vb::chunk_load(Ag, gA, sA, ra);
+    vb::chunk_load(Bg, gB, sB, rb);
+    vb::chunk_store<A_KMAJOR>(Asb, lA, ra);
+    vb::chunk_store<B_KMAJOR>(Bsb, lB, rb);
+  }
+  __syncthreads();
+
+  const int kq = lane >> 4, l15 = lane & 15;
+  const double* a_ptr = As + kq * LDS_LD + wr * 64 + l15;
+  const double* b_ptr = Bs + kq * LDS_LD + wc * 64 + l15;
+  double af[2][4], bf[2][4];
+  auto load_frags = [&](int set, int boff, int kk) {
+    const double* ap = a_ptr + boff + kk * 4 * LDS_LD;
+    const double* bp = b_ptr + boff + kk * 4 * LDS_LD;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) af[set][a] = ap[16 * a];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) bf[set][b] = bp[16 * b];
+  };
+  if (nchunk > 0) load_frags(0, 0, 0);
+
+  for (int c = 0; c < nchunk; ++c) {
+    const int boff = (c & 1) * OPER_B;
+    const bool more = (c + 1 < nchunk);
+    if (more) {
+      Ag += stepA;
+      Bg += stepB;
+      vb::chunk_load(Ag, gA, sA, ra);
+      vb::chunk_load(Bg, gB, sB, rb);
+    }
+#pragma unroll
+    for (int kk = 0; kk < BKB / 4; ++kk) {
+      const int cur = kk & 1;
+      if (kk + 1 < BKB / 4) load_frags(cur ^ 1, boff, kk + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur][a], bf[cur][b], acc[a][b], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kk == BKB / 4 - 2 && more) {
+        const int noff = (boff ^ OPER_B) * 8;
+        vb::chunk_store<A_KMAJOR>(Asb + noff, lA, ra);
+        vb::chunk_store<B_KMAJOR>(Bsb + noff, lB, rb);
+      }
+    }
+    __syncthreads();
+    if (more) load_frags(0, boff ^ OPER_B, 0);
+  }
+
+  const double alpha = p.alpha, beta = p.beta;
+  double* cbase = C + (long)(i0 + wr * 64 + kq) * p.ldc + j0 + wc * 64 + l15;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    if (beta != 0.0) {
+      double4_t cv[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cv[b][r] = cbase[(long)(16 * a + 4 * r) * p.ldc + 16 * b];
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          cbase[(long)(16 * a + 4 * r) * p.ldc + 16 * b] = alpha * acc[a][b][r] + beta * cv[b][r];
+    } else {
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cbase[(long)(16 * a + 4 * r) * p.ldc + 16 * b] = alpha * acc[a][b][r];
+    }
+  }
+}
+
 static int tile_count(const GemmParams& p) {
   if (!p.tri) return p.mt * p.nt;
   return p.nt * (p.nt + 1) / 2 + (p.mt - p.nt) * p.nt;
 }
 
+static int g_variant = -1;
+static int gemm_variant() {
+  if (g_variant < 0) {
+    const char* e = getenv("MIGP_GEMM_VARIANT");
+    g_variant = (e && e[0] == 'A') ? 0 : 1;
+  }
+  return g_variant;
+}
+
+void set_gemm_variant(int v) { g_variant = v; }
+
 hipError_t launch_gemm_f64(const GemmParams& p, int opA_kmajor, int opB_kmajor, int batch, hipStream_t stream) {
   const int nblk = tile_count(p);
   if (nblk <= 0 || batch <= 0) return hipSuccess;
+  if (gemm_variant() == 1) {
+    dim3 grid(nblk, 1, batch), block(vb::NT_B);
+    const size_t lds = sizeof(double) * 4 * vb::OPER_B;
+    if (!opA_kmajor && !opB_kmajor) gemm_f64_kernel_b<false, false><<<grid, block, lds, stream>>>(p);
+    else if (!opA_kmajor && opB_kmajor) gemm_f64_kernel_b<false, true><<<grid, block, lds, stream>>>(p);
+    else if (opA_kmajor && opB_kmajor) gemm_f64_kernel_b<true, true><<<grid, block, lds, stream>>>(p);
+    else gemm_f64_kernel_b<true, false><<<grid, block, lds, stream>>>(p);
+    return hipGetLastError();
+  }
   dim3 grid(nblk, 1, batch), block(NTHREADS);
   const size_t lds = sizeof(double) * 4 * OPER_ELEMS;
   if (!opA_kmajor && !opB_kmajor) gemm_f64_kernel<false, false><<<grid, block, lds, stream>>>(p);
@@ -257,16 +446,26 @@ hipError_t launch_gemm_f64(const GemmParams& p, int opA_kmajor, int opB_kmajor, 
 }
 
 hipError_t gemm_f64_enable_lds() {
-  // 72 KiB of dynamic LDS per workgroup needs the opt-in attribute.
-  const int lds = (int)(sizeof(double) * 4 * OPER_ELEMS);
   hipError_t e;
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  {
+    const int lds = (int)(sizeof(double) * 4 * OPER_ELEMS);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+  }
+  const int ldsb = (int)(sizeof(double) * 4 * vb::OPER_B);
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_kernel_b<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);
   if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_kernel_b<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);
   if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_kernel_b<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);
   if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_kernel_b<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);
 }
 
 }  // namespace migp

@@ -14,8 +14,16 @@ namespace migp {
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 constexpr int LEAF = 128;
-constexpr int LEAF_LD = 130;  // LDS leading dimension (rows stay 16-byte aligned)
 constexpr int SB = 16;        // sub-block width
+// LDS image of the leaf: only the lower block-trapezoid is kept.  Row block b (rows 16b..16b+15)
+// stores columns 0..16(b+1)-1 with row stride 16b+18 doubles (16-byte aligned, and 18 or 2 mod 32 so
+// that 16 consecutive rows read at one column hit 16 distinct bank pairs).  75.8 KB instead of 133 KB:
+// the leaf can then share a CU with one 72 KB GEMM workgroup instead of waiting for an empty CU.
+constexpr int LEAF_ELEMS = 9472;  // sum_b 16 * (16 (b+1) + 2)
+__device__ __forceinline__ int soff(int row) {
+  const int b = row >> 4;
+  return 128 * b * (b + 1) + 32 * b + (row & 15) * (16 * b + 18);
+}
 
 // 1/sqrt(x) for normal positive x: hardware seed (v_rsq_f64) + two Goldschmidt steps + one
 // Newton correction; ~1 ulp, about 15 dependent FMAs instead of the ~80-instruction
@@ -148,8 +156,8 @@ __global__ __launch_bounds__(256, 1) void potrf_leaf128_kernel(double* __restric
                                                                 double* __restrict__ dinv, int col0,
                                                                 int* __restrict__ info) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  double* S = smem;                     // [128][LEAF_LD]
-  double* LdT = smem + LEAF * LEAF_LD;  // [16][16]  LdT[k][c] = L16[c][k] (current diagonal sub-block)
+  double* S = smem;                     // packed lower block-trapezoid, see soff()
+  double* LdT = smem + LEAF_ELEMS;      // [16][16]  LdT[k][c] = L16[c][k] (current diagonal sub-block)
   double* invd = LdT + SB * SB;         // [128] 1 / L[c][c]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -159,7 +167,7 @@ __global__ __launch_bounds__(256, 1) void potrf_leaf128_kernel(double* __restric
   if (threadIdx.x == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory");
 #endif
 
-  // load the whole 128x128 block (the strict upper triangle is never used), 16 B per lane per load
+  // load the lower block-trapezoid, 16 B per lane per load, 8 loads in flight
   {
     typedef double double2_t __attribute__((ext_vector_type(2)));
     double2_t v[8];
@@ -168,12 +176,14 @@ __global__ __launch_bounds__(256, 1) void potrf_leaf128_kernel(double* __restric
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const int e = tid + 256 * (q + 8 * h);  // 16-byte piece index: row = e >> 6, col pair = e & 63
-        v[q] = *reinterpret_cast<const double2_t*>(Ablk + (long)(e >> 6) * lda + 2 * (e & 63));
+        const int r = e >> 6, c2 = 2 * (e & 63);
+        if (c2 < 16 * ((r >> 4) + 1)) v[q] = *reinterpret_cast<const double2_t*>(Ablk + (long)r * lda + c2);
       }
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const int e = tid + 256 * (q + 8 * h);
-        *reinterpret_cast<double2_t*>(S + (e >> 6) * LEAF_LD + 2 * (e & 63)) = v[q];
+        const int r = e >> 6, c2 = 2 * (e & 63);
+        if (c2 < 16 * ((r >> 4) + 1)) *reinterpret_cast<double2_t*>(S + soff(r) + c2) = v[q];
       }
     }
   }
@@ -187,7 +197,7 @@ __global__ __launch_bounds__(256, 1) void potrf_leaf128_kernel(double* __restric
       const int r = lane & 15;
       double a[SB];
       {
-        const double* row = S + (j0 + r) * LEAF_LD + j0;
+        const double* row = S + soff(j0 + r) + j0;
 #pragma unroll
         for (int c = 0; c < SB; ++c) a[c] = row[c];
       }
@@ -198,7 +208,7 @@ __global__ __launch_bounds__(256, 1) void potrf_leaf128_kernel(double* __restric
       const double rs = fast_rsqrt(a[r]);
       double l[SB];
       ScaleCols<0>::run(a, rs, l);
-      double* row = S + (j0 + r) * LEAF_LD + j0;
+      double* row = S + soff(j0 + r) + j0;
 #pragma unroll
       for (int c = 0; c < SB; ++c) {
         if (lane < SB && c <= r) {
@@ -214,7 +224,7 @@ __global__ __launch_bounds__(256, 1) void potrf_leaf128_kernel(double* __restric
     {
       const int nrow = LEAF - j0 - SB;  // rows j0+16 .. 127
       if (tid < nrow) {
-        double* row = S + (j0 + SB + tid) * LEAF_LD + j0;
+        double* row = S + soff(j0 + SB + tid) + j0;
         double x[SB];
 #pragma unroll
         for (int c = 0; c < SB; ++c) x[c] = row[c];
@@ -243,15 +253,15 @@ __global__ __launch_bounds__(256, 1) void potrf_leaf128_kernel(double* __restric
           double av[4], bv[4];
 #pragma unroll
           for (int s4 = 0; s4 < 4; ++s4) {
-            av[s4] = S[(r0 + n) * LEAF_LD + j0 + 4 * s4 + kq];  // X[r0 + (l&15)][k = 4s + (l>>4)]
-            bv[s4] = S[(c0 + n) * LEAF_LD + j0 + 4 * s4 + kq];  // X[c0 + (l&15)][k]
+            av[s4] = S[soff(r0 + n) + j0 + 4 * s4 + kq];  // X[r0 + (l&15)][k = 4s + (l>>4)]
+            bv[s4] = S[soff(c0 + n) + j0 + 4 * s4 + kq];  // X[c0 + (l&15)][k]
           }
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc[r] = S[(r0 + kq + 4 * r) * LEAF_LD + c0 + n];
+          for (int r = 0; r < 4; ++r) acc[r] = S[soff(r0 + kq + 4 * r) + c0 + n];
 #pragma unroll
           for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[s4], bv[s4], acc, 0, 0, 0);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) S[(r0 + kq + 4 * r) * LEAF_LD + c0 + n] = acc[r];
+          for (int r = 0; r < 4; ++r) S[soff(r0 + kq + 4 * r) + c0 + n] = acc[r];
         }
       }
     }
@@ -267,7 +277,7 @@ __global__ __launch_bounds__(256, 1) void potrf_leaf128_kernel(double* __restric
       const int e = tid + 256 * it;
       const int r = e >> 6, c2 = 2 * (e & 63);
       if (c2 <= r) {
-        const double2_t v = *reinterpret_cast<const double2_t*>(S + r * LEAF_LD + c2);
+        const double2_t v = *reinterpret_cast<const double2_t*>(S + soff(r) + c2);
         double* dst = Ablk + (long)r * lda + c2;
         if (c2 + 1 <= r) *reinterpret_cast<double2_t*>(dst) = v;
         else dst[0] = v.x;
@@ -283,7 +293,7 @@ __global__ __launch_bounds__(256, 1) void potrf_leaf128_kernel(double* __restric
     for (int r = 0; r < SB; ++r) z[r] = 0.0;
 #pragma unroll
     for (int r = 0; r < SB; ++r) {
-      const double* lrow = S + (j0 + r) * LEAF_LD + j0;
+      const double* lrow = S + soff(j0 + r) + j0;
       double s0 = (r == c) ? 1.0 : 0.0, s1 = 0.0;
 #pragma unroll
       for (int k = 0; k < r; ++k) {  // z[k] = 0 for k < c, so no predicate is needed
@@ -301,26 +311,17 @@ __global__ __launch_bounds__(256, 1) void potrf_leaf128_kernel(double* __restric
 
 // X * L^T = B, in place on B (m x 128, leading dimension ldb, m multiple of 64).
 // One wave per 16 rows; tiles kept transposed: T_j[r] = B[row0 + (l&15)][16j + 4r + (l>>4)].
-__global__ __launch_bounds__(256, 1) void trsm_strip128_kernel(const double* __restrict__ Lblk, long lda,
-                                                                const double* __restrict__ dinv,
-                                                                double* __restrict__ B, long ldb, long strideL,
-                                                                long strideB) {
+// The L fragments (MFMA A operands) are read straight from L2 -- no LDS, so strip workgroups can
+// share CUs with GEMM workgroups of the concurrent trailing update -- one block column ahead.
+__global__ __launch_bounds__(256) void trsm_strip128_kernel(const double* __restrict__ Lblk, long lda,
+                                                             const double* __restrict__ dinv,
+                                                             double* __restrict__ B, long ldb, long strideL,
+                                                             long strideB) {
   Lblk += (long)blockIdx.y * strideL;
   dinv += (long)blockIdx.y * 2048;
   B += (long)blockIdx.y * strideB;
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  double* Ls = smem;  // [128][LEAF_LD] lower triangle of L
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  for (int e = tid; e < LEAF * (LEAF / 2); e += 256) {
-    const int r = e >> 6, c2 = (e & 63) * 2;
-    if (c2 <= r) {
-      const double* src = Lblk + (long)r * lda + c2;
-      Ls[r * LEAF_LD + c2] = src[0];
-      Ls[r * LEAF_LD + c2 + 1] = src[1];
-    }
-  }
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
   const int n = lane & 15, q = lane >> 4;
   double* Brow = B + ((long)blockIdx.x * 64 + wave * 16 + n) * ldb;
   double4_t T[8];
@@ -328,28 +329,34 @@ __global__ __launch_bounds__(256, 1) void trsm_strip128_kernel(const double* __r
   for (int j = 0; j < 8; ++j)
 #pragma unroll
     for (int r = 0; r < 4; ++r) T[j][r] = Brow[16 * j + 4 * r + q];
-  __syncthreads();
-
+  // fragment (i, j, s): L[16i + (l&15)][16j + 4s + (l>>4)]
+  const double* Lfrag = Lblk + (long)n * lda + q;
+  double4_t La[2][7];  // double buffer over block columns j: La[j&1][i-j-1][s]
+  double4_t Dj[2];
+  auto load_col = [&](int set, int j) {
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) Dj[set][s4] = dinv[j * SB * SB + n * SB + 4 * s4 + q];
+#pragma unroll
+    for (int i = j + 1; i < 8; ++i)
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) La[set][i - j - 1][s4] = Lfrag[(long)(16 * i) * lda + 16 * j + 4 * s4];
+  };
+  load_col(0, 0);
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
+    const int cur = j & 1;
+    if (j + 1 < 8) load_col(cur ^ 1, j + 1);
     // X_j = Dinv_j * T_j
     double4_t X = {0.0, 0.0, 0.0, 0.0};
-    const double* dj = dinv + j * SB * SB;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const double a = dj[n * SB + 4 * s + q];  // Dinv_j[i = l&15][k = 4s + (l>>4)]
-      X = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T[j][s], X, 0, 0, 0);
-    }
+    for (int s4 = 0; s4 < 4; ++s4) X = __builtin_amdgcn_mfma_f64_16x16x4f64(Dj[cur][s4], T[j][s4], X, 0, 0, 0);
     T[j] = X;
     const double4_t Xn = -X;
 #pragma unroll
-    for (int i = j + 1; i < 8; ++i) {
+    for (int i = j + 1; i < 8; ++i)
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const double a = Ls[(16 * i + n) * LEAF_LD + 16 * j + 4 * s + q];  // L[16i + (l&15)][16j + 4s + (l>>4)]
-        T[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Xn[s], T[i], 0, 0, 0);
-      }
-    }
+      for (int s4 = 0; s4 < 4; ++s4)
+        T[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(La[cur][i - j - 1][s4], Xn[s4], T[i], 0, 0, 0);
   }
 #pragma unroll
   for (int j = 0; j < 8; ++j)
@@ -357,15 +364,13 @@ __global__ __launch_bounds__(256, 1) void trsm_strip128_kernel(const double* __r
     for (int r = 0; r < 4; ++r) Brow[16 * j + 4 * r + q] = T[j][r];
 }
 
-constexpr size_t LEAF_LDS_BYTES = sizeof(double) * (LEAF * LEAF_LD + SB * SB + LEAF);
-constexpr size_t STRIP_LDS_BYTES = sizeof(double) * (LEAF * LEAF_LD);
+constexpr size_t LEAF_LDS_BYTES = sizeof(double) * (LEAF_ELEMS + SB * SB + LEAF);
+constexpr size_t STRIP_LDS_BYTES = 0;
 
 hipError_t leaf_enable_lds() {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_leaf128_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAF_LDS_BYTES);
-  if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(trsm_strip128_kernel),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)STRIP_LDS_BYTES);
+  return e;
 }
 
 hipError_t launch_potrf_leaf128(double* Ablk, long lda, double* dinv, int col0, int* info, hipStream_t stream) {

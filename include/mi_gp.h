@@ -86,6 +86,11 @@ int mi_gp_factor(mi_gp_handle* h, const double* theta_host);
 int mi_gp_predict(mi_gp_handle* h, const double* Xnew_dev, int m, double* work_dev, long ldw, double* mean_dev,
                   double* var_dev, int pred_noise);
 
+/* tuning knobs (benchmarks / A-B tests): what = 0 one-super-panel look-ahead on the second stream
+ * (per handle, default 1); 1 GEMM kernel variant (process-wide: 0 = 8 waves, 1 workgroup per CU;
+ * 1 = 4 waves, 2 workgroups per CU, default); 2 super-panel width in 128-column tiles. */
+int mi_gp_set_option(mi_gp_handle* h, int what, int value);
+
 /* profiling: level 0 none, 1 per-phase HIP events, 2 additionally per-GEMM-launch HIP events */
 int mi_gp_set_profiling(mi_gp_handle* h, int level);
 /* out[0..9] = assemble_ms, cholesky_ms, reduce_ms, total_ms, gemm_ms (sum over launches),

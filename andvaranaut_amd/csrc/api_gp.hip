@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <vector>
 #include "migp_kernels.h"
 #include "../../include/mi_gp.h"
@@ -20,6 +21,8 @@ struct mi_gp_handle {
   hipStream_t pstream;   // look-ahead panel factorisation (higher priority)
   hipEvent_t ev_panel, ev_upd;
   int lookahead;
+  int use_graph;
+  std::map<int, hipGraphExec_t> graphs;  // captured evaluation DAGs, keyed by (what, options)
   mi_gp_buffers buf;
   bool have_data;
   // handle-owned small scratch
@@ -92,6 +95,7 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_panel, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_upd, hipEventDisableTiming);
   h->lookahead = 1;
+  h->use_graph = 1;
   if (e == hipSuccess) e = hipMalloc(&h->theta_dev, sizeof(double) * h->ntheta);
   if (e == hipSuccess) e = hipMalloc(&h->out_dev, sizeof(double) * 16);
   if (e == hipSuccess) e = hipMalloc(&h->dinv_dev, sizeof(double) * 2048 * (size_t)h->ntc);
@@ -125,6 +129,7 @@ extern "C" int mi_gp_destroy(mi_gp_handle* h) {
   hipHostFree(h->out_host); hipHostFree(h->info_host); hipHostFree(h->theta_host);
   for (int i = 0; i < 8; ++i) hipEventDestroy(h->ev[i]);
   for (auto& ev : h->gemm_ev) hipEventDestroy(ev);
+  for (auto& kv : h->graphs) if (kv.second) hipGraphExecDestroy(kv.second);
   hipEventDestroy(h->ev_panel); hipEventDestroy(h->ev_upd);
   hipStreamDestroy(h->pstream);
   hipStreamDestroy(h->stream);
@@ -144,6 +149,8 @@ extern "C" int mi_gp_set_data(mi_gp_handle* h, const mi_gp_buffers* b) {
   }
   h->buf = *b;
   h->have_data = true;
+  for (auto& kv : h->graphs) if (kv.second) hipGraphExecDestroy(kv.second);  // captured pointers are stale
+  h->graphs.clear();
   return 0;
 }
 
@@ -154,6 +161,7 @@ extern "C" int mi_gp_set_option(mi_gp_handle* h, int what, int value) {
   if (what == 0) h->lookahead = value ? 1 : 0;
   else if (what == 1) set_gemm_variant(value);
   else if (what == 2) h->cfg.panel_tiles = value;
+  else if (what == 3) h->use_graph = value ? 1 : 0;
   else return -1;
   return 0;
 }
@@ -265,25 +273,10 @@ static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int nt
   return hipSuccess;
 }
 
-static int upload_theta(mi_gp_handle* h, const double* theta) {
-  for (int i = 0; i < h->ntheta; ++i) {
-    if (!std::isfinite(theta[i])) { snprintf(h->err, sizeof(h->err), "theta[%d] is not finite", i); return -1; }
-    h->theta_host[i] = theta[i];
-  }
-  HCK(hipMemcpyAsync(h->theta_dev, h->theta_host, sizeof(double) * h->ntheta, hipMemcpyHostToDevice, h->stream), "theta upload");
-  return 0;
-}
-
-// assemble + factor the augmented trapezoid [[K],[y^T]]; leaves L in K_dev, beta = L^-1 y in row np
-static int factor_internal(mi_gp_handle* h, const double* theta, int noise_form) {
-  h->factored = false;
-  if (!h->have_data) { snprintf(h->err, sizeof(h->err), "mi_gp_set_data has not been called"); return -1; }
-  HCK(hipSetDevice(h->device), "hipSetDevice");
-  if (int r = upload_theta(h, theta)) return r;
-  const bool prof = h->prof_level >= 1;
-  h->gemm_ev_used = 0;
-  h->gemm_flops_acc = 0.0;
-  HCK(hipMemsetAsync(h->info_dev, 0x7f, sizeof(int) * 4, h->stream), "info reset");
+// Kernels of one evaluation: assembly, factorisation of the augmented trapezoid [[K],[y^T]] (L ends
+// up in K_dev, beta = L^-1 y in row np), reduction.  Only kernels -- the small copies around them
+// stay outside the captured graph.
+static int enqueue_factor(mi_gp_handle* h, int noise_form, bool prof) {
   if (prof) hipEventRecord(h->ev[0], h->stream);
   HCK(launch_assemble(h->spec, h->theta_dev, h->buf.X_dev, h->n, h->buf.X_dev, h->n, h->buf.K_dev, h->buf.lda, h->np,
                       h->np, 1, noise_form, h->stream), "assemble");
@@ -293,8 +286,95 @@ static int factor_internal(mi_gp_handle* h, const double* theta, int noise_form)
   if (prof) hipEventRecord(h->ev[2], h->stream);
   HCK(launch_lml_reduce(h->buf.K_dev, h->buf.lda, h->buf.K_dev + (long)h->np * h->buf.lda, h->n, h->out_dev, h->stream), "lml_reduce");
   if (prof) hipEventRecord(h->ev[3], h->stream);
+  return 0;
+}
+
+static int enqueue_gradient(mi_gp_handle* h, bool prof);
+static hipError_t inverse_transpose(mi_gp_handle* h);
+
+static int download_results(mi_gp_handle* h, int what) {
   HCK(hipMemcpyAsync(h->out_host, h->out_dev, sizeof(double) * 16, hipMemcpyDeviceToHost, h->stream), "out download");
   HCK(hipMemcpyAsync(h->info_host, h->info_dev, sizeof(int) * 4, hipMemcpyDeviceToHost, h->stream), "info download");
+  if (what == 2)
+    HCK(hipMemcpyAsync(h->grad_host, h->grad_dev, sizeof(double) * h->ntheta, hipMemcpyDeviceToHost, h->stream), "grad download");
+  return 0;
+}
+
+// Run `what` (0 factor marginal form, 1 factor conditional form, 2 factor + gradient) either by
+// replaying its captured hipGraph (the DAG is static for a handle: only theta changes, and theta
+// travels through a fixed pinned buffer) or, when profiling events are requested, by plain launches.
+static int run_evaluation(mi_gp_handle* h, int what) {
+  const bool prof = h->prof_level >= 1;
+  const int noise_form = (what == 1) ? 1 : 0;
+  h->gemm_ev_used = 0;
+  h->gemm_flops_acc = 0.0;
+  HCK(hipMemcpyAsync(h->theta_dev, h->theta_host, sizeof(double) * h->ntheta, hipMemcpyHostToDevice, h->stream), "theta upload");
+  HCK(hipMemsetAsync(h->info_dev, 0x7f, sizeof(int) * 4, h->stream), "info reset");
+  if (prof || !h->use_graph) {
+    if (int r = enqueue_factor(h, noise_form, prof)) return r;
+    if (what == 2) { if (int r = enqueue_gradient(h, prof)) return r; }
+    return download_results(h, what);
+  }
+  const int W = h->cfg.panel_tiles > 0 ? h->cfg.panel_tiles : 4;
+  const int key = what | (h->lookahead << 4) | (W << 8) | (gemm_variant_get() << 20);
+  auto it = h->graphs.find(key);
+  if (it == h->graphs.end()) {
+    // First use: time one evaluation with plain launches, then capture + instantiate and time a
+    // replay.  On ROCm 7.2 some instantiations of this two-branch DAG replay ~40 % slower than
+    // plain launches (the look-ahead branch loses its overlap), others ~3-5 % faster; keep an
+    // executable graph only if it is not slower, retry a couple of times, else fall back (nullptr).
+    float t_plain = 0.f;
+    hipEventRecord(h->ev[0], h->stream);
+    if (int r = enqueue_factor(h, noise_form, false)) return r;
+    if (what == 2) { if (int r = enqueue_gradient(h, false)) return r; }
+    hipEventRecord(h->ev[1], h->stream);
+    HCK(hipStreamSynchronize(h->stream), "sync");
+    hipEventElapsedTime(&t_plain, h->ev[0], h->ev[1]);
+    hipGraphExec_t keep = nullptr;
+    for (int attempt = 0; attempt < 3 && !keep; ++attempt) {
+      hipGraph_t graph = nullptr;
+      HCK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal), "begin capture");
+      int r = enqueue_factor(h, noise_form, false);
+      if (r == 0 && what == 2) r = enqueue_gradient(h, false);
+      hipError_t e = hipStreamEndCapture(h->stream, &graph);
+      if (r != 0) { if (graph) hipGraphDestroy(graph); return r; }
+      if (e != hipSuccess) return hfail(h, e, "end capture");
+      hipGraphExec_t exec = nullptr;
+      e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+      hipGraphDestroy(graph);
+      if (e != hipSuccess) return hfail(h, e, "graph instantiate");
+      float t_graph = 0.f;
+      HCK(hipMemsetAsync(h->info_dev, 0x7f, sizeof(int) * 4, h->stream), "info reset");
+      hipEventRecord(h->ev[0], h->stream);
+      HCK(hipGraphLaunch(exec, h->stream), "graph launch");
+      hipEventRecord(h->ev[1], h->stream);
+      HCK(hipStreamSynchronize(h->stream), "sync");
+      hipEventElapsedTime(&t_graph, h->ev[0], h->ev[1]);
+      if (t_graph <= 1.05f * t_plain) keep = exec;
+      else hipGraphExecDestroy(exec);
+    }
+    h->graphs.emplace(key, keep);
+    return download_results(h, what);  // the last run (plain or replay) left valid results
+  }
+  if (it->second == nullptr) {
+    if (int r = enqueue_factor(h, noise_form, false)) return r;
+    if (what == 2) { if (int r = enqueue_gradient(h, false)) return r; }
+    return download_results(h, what);
+  }
+  HCK(hipGraphLaunch(it->second, h->stream), "graph launch");
+  return download_results(h, what);
+}
+
+static int factor_internal(mi_gp_handle* h, const double* theta, int what) {
+  h->factored = false;
+  if (!h->have_data) { snprintf(h->err, sizeof(h->err), "mi_gp_set_data has not been called"); return -1; }
+  HCK(hipSetDevice(h->device), "hipSetDevice");
+  for (int i = 0; i < h->ntheta; ++i) {
+    if (!std::isfinite(theta[i])) { snprintf(h->err, sizeof(h->err), "theta[%d] is not finite", i); return -1; }
+    h->theta_host[i] = theta[i];
+  }
+  const bool prof = h->prof_level >= 1;
+  if (int r = run_evaluation(h, what)) return r;
   HCK(hipStreamSynchronize(h->stream), "stream sync");
   if (prof) {
     float ms;
@@ -310,6 +390,11 @@ static int factor_internal(mi_gp_handle* h, const double* theta, int noise_form)
     h->t_gemm_ms = g;
     h->gemm_flops = h->gemm_flops_acc;
     h->n_gemm = (double)(h->gemm_ev_used / 2);
+    if (what == 2) {
+      hipEventElapsedTime(&ms, h->ev[4], h->ev[5]); h->t_trtri_ms = ms;
+      hipEventElapsedTime(&ms, h->ev[5], h->ev[6]); h->t_lauum_ms = ms;
+      hipEventElapsedTime(&ms, h->ev[6], h->ev[7]); h->t_contract_ms = ms;
+    }
   }
   const int info = h->info_host[0];
   if (info != 0x7f7f7f7f) return info;  // 1-based index of the first bad pivot
@@ -393,18 +478,8 @@ static hipError_t inverse_transpose(mi_gp_handle* h) {
   return hipSuccess;
 }
 
-extern "C" int mi_gp_lml_grad(mi_gp_handle* h, const double* theta, double* lml_out, double* grad_out) {
-  if (!h || !theta || !lml_out || !grad_out) return -1;
-  if (!h->buf.Z_dev || !h->buf.W_dev) {
-    snprintf(h->err, sizeof(h->err), "mi_gp_lml_grad needs Z_dev and W_dev in mi_gp_set_data");
-    return -1;
-  }
-  const int r = factor_internal(h, theta, 0);
-  if (r < 0) return r;
-  for (int i = 0; i < h->ntheta; ++i) grad_out[i] = 0.0;
-  if (r > 0) { *lml_out = -INFINITY; return r; }
-  *lml_out = h->out_host[0];
-  const bool prof = h->prof_level >= 1;
+// everything after the factorisation: U = L^-T, Kinv = U U^T, alpha = U beta, contraction, download
+static int enqueue_gradient(mi_gp_handle* h, bool prof) {
   if (prof) hipEventRecord(h->ev[4], h->stream);
   HCK(inverse_transpose(h), "inverse_transpose");
   if (prof) hipEventRecord(h->ev[5], h->stream);
@@ -417,15 +492,23 @@ extern "C" int mi_gp_lml_grad(mi_gp_handle* h, const double* theta, double* lml_
   HCK(launch_grad_contract(h->spec, h->theta_dev, h->buf.X_dev, h->n, h->buf.W_dev, ld, h->alpha_dev, h->part_dev,
                            h->grad_dev, h->stream), "grad_contract");
   if (prof) hipEventRecord(h->ev[7], h->stream);
-  HCK(hipMemcpyAsync(h->grad_host, h->grad_dev, sizeof(double) * h->ntheta, hipMemcpyDeviceToHost, h->stream), "grad download");
-  HCK(hipStreamSynchronize(h->stream), "stream sync");
-  for (int i = 0; i < h->ntheta; ++i) grad_out[i] = h->grad_host[i];
-  if (prof) {
-    float ms;
-    hipEventElapsedTime(&ms, h->ev[4], h->ev[5]); h->t_trtri_ms = ms;
-    hipEventElapsedTime(&ms, h->ev[5], h->ev[6]); h->t_lauum_ms = ms;
-    hipEventElapsedTime(&ms, h->ev[6], h->ev[7]); h->t_contract_ms = ms;
+  return 0;
+}
+
+extern "C" int mi_gp_lml_grad(mi_gp_handle* h, const double* theta, double* lml_out, double* grad_out) {
+  if (!h || !theta || !lml_out || !grad_out) return -1;
+  if (!h->buf.Z_dev || !h->buf.W_dev) {
+    snprintf(h->err, sizeof(h->err), "mi_gp_lml_grad needs Z_dev and W_dev in mi_gp_set_data");
+    return -1;
   }
+  // the gradient kernels run unconditionally behind the factorisation (one captured DAG); on a
+  // non-positive-definite K their output is discarded
+  const int r = factor_internal(h, theta, 2);
+  if (r < 0) return r;
+  for (int i = 0; i < h->ntheta; ++i) grad_out[i] = 0.0;
+  if (r > 0) { *lml_out = -INFINITY; return r; }
+  *lml_out = h->out_host[0];
+  for (int i = 0; i < h->ntheta; ++i) grad_out[i] = h->grad_host[i];
   return 0;
 }
 

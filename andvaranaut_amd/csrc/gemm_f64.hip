@@ -423,6 +423,7 @@ static int gemm_variant() {
 }
 
 void set_gemm_variant(int v) { g_variant = v; }
+int gemm_variant_get() { return gemm_variant(); }
 
 hipError_t launch_gemm_f64(const GemmParams& p, int opA_kmajor, int opB_kmajor, int batch, hipStream_t stream) {
   const int nblk = tile_count(p);

@@ -88,7 +88,8 @@ int mi_gp_predict(mi_gp_handle* h, const double* Xnew_dev, int m, double* work_d
 
 /* tuning knobs (benchmarks / A-B tests): what = 0 one-super-panel look-ahead on the second stream
  * (per handle, default 1); 1 GEMM kernel variant (process-wide: 0 = 8 waves, 1 workgroup per CU;
- * 1 = 4 waves, 2 workgroups per CU, default); 2 super-panel width in 128-column tiles. */
+ * 1 = 4 waves, 2 workgroups per CU, default); 2 super-panel width in 128-column tiles;
+ * 3 replay each evaluation from a captured hipGraph (default 1; profiling levels >= 1 use plain launches). */
 int mi_gp_set_option(mi_gp_handle* h, int what, int value);
 
 /* profiling: level 0 none, 1 per-phase HIP events, 2 additionally per-GEMM-launch HIP events */

@@ -22,6 +22,7 @@ struct mi_gp_handle {
   hipEvent_t ev_panel, ev_upd;
   int lookahead;
   int use_graph;
+  int w_thr[3];  // trailing sizes (tile columns) above which the super-panel is 8 / 4 / 2 tiles wide
   std::map<int, hipGraphExec_t> graphs;  // captured evaluation DAGs, keyed by (what, options)
   mi_gp_buffers buf;
   bool have_data;
@@ -96,6 +97,7 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_upd, hipEventDisableTiming);
   h->lookahead = 1;
   h->use_graph = 1;
+  h->w_thr[0] = 72; h->w_thr[1] = 0; h->w_thr[2] = 0;
   if (e == hipSuccess) e = hipMalloc(&h->theta_dev, sizeof(double) * h->ntheta);
   if (e == hipSuccess) e = hipMalloc(&h->out_dev, sizeof(double) * 16);
   if (e == hipSuccess) e = hipMalloc(&h->dinv_dev, sizeof(double) * 2048 * (size_t)h->ntc);
@@ -162,6 +164,7 @@ extern "C" int mi_gp_set_option(mi_gp_handle* h, int what, int value) {
   else if (what == 1) set_gemm_variant(value);
   else if (what == 2) h->cfg.panel_tiles = value;
   else if (what == 3) h->use_graph = value ? 1 : 0;
+  else if (what >= 4 && what <= 6) h->w_thr[what - 4] = value;
   else return -1;
   return 0;
 }
@@ -240,8 +243,16 @@ static hipError_t chol_panel(mi_gp_handle* h, double* A, long lda, int ntr, int 
 // Right-looking blocked Cholesky of the (ntr x ntc)-tile lower trapezoid with one super-panel of
 // look-ahead: while the trailing update of super-panel J runs on the main stream, the next
 // super-panel (whose columns were updated first) is factored on the high-priority panel stream.
+// super-panel width (128-column tiles) for a trailing matrix of `rem` tile columns: wide panels while
+// the trailing update is long enough to hide their factorisation (k = 1024 runs the GEMM at ~64
+// TFLOP/s instead of ~57 at k = 512), narrower ones once the panel chain is the critical path
+static int pick_w(const mi_gp_handle* h, int rem) {
+  int W = h->cfg.panel_tiles;
+  if (W <= 0) W = (rem > h->w_thr[0]) ? 8 : (rem > h->w_thr[1]) ? 4 : (rem > h->w_thr[2]) ? 2 : 1;
+  return rem < W ? rem : W;
+}
+
 static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int ntc) {
-  const int W = h->cfg.panel_tiles > 0 ? h->cfg.panel_tiles : 4;
   hipStream_t T = h->stream, P = h->lookahead ? h->pstream : h->stream;
   hipError_t e;
 #define CKE(x) do { e = (x); if (e != hipSuccess) return e; } while (0)
@@ -249,16 +260,16 @@ static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int nt
     CKE(hipEventRecord(h->ev_upd, T));
     CKE(hipStreamWaitEvent(P, h->ev_upd, 0));
   }
-  CKE(chol_panel(h, A, lda, ntr, 0, ntc < W ? ntc : W, P));
-  for (int J = 0; J < ntc; J += W) {
-    const int w = (ntc - J < W) ? (ntc - J) : W;
+  int w = pick_w(h, ntc);
+  CKE(chol_panel(h, A, lda, ntr, 0, w, P));
+  for (int J = 0; J < ntc;) {
     const int n1 = J + w;  // first tile column right of this super-panel
     if (P != T) {
       CKE(hipEventRecord(h->ev_panel, P));
       CKE(hipStreamWaitEvent(T, h->ev_panel, 0));
     }
     if (n1 >= ntc) break;
-    const int wn = (ntc - n1 < W) ? (ntc - n1) : W;
+    const int wn = pick_w(h, ntc - n1);
     // (a) bring the next super-panel's columns up to date, then hand them to the panel stream
     CKE(syrk_trapezoid(h, A, lda, ntr, n1, wn, J, w, T));
     if (P != T) {
@@ -268,6 +279,8 @@ static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int nt
     CKE(chol_panel(h, A, lda, ntr, n1, wn, P));
     // (b) the rest of the trailing matrix, concurrently with that panel factorisation
     if (n1 + wn < ntc) CKE(syrk_trapezoid(h, A, lda, ntr, n1 + wn, ntc - n1 - wn, J, w, T));
+    J = n1;
+    w = wn;
   }
 #undef CKE
   return hipSuccess;
@@ -315,8 +328,8 @@ static int run_evaluation(mi_gp_handle* h, int what) {
     if (what == 2) { if (int r = enqueue_gradient(h, prof)) return r; }
     return download_results(h, what);
   }
-  const int W = h->cfg.panel_tiles > 0 ? h->cfg.panel_tiles : 4;
-  const int key = what | (h->lookahead << 4) | (W << 8) | (gemm_variant_get() << 20);
+  const int key = what | (h->lookahead << 4) | ((h->cfg.panel_tiles & 0xff) << 8) | (gemm_variant_get() << 20) |
+                  ((h->w_thr[0] * 31 + h->w_thr[1] * 7 + h->w_thr[2]) & 0x7ff) << 21;
   auto it = h->graphs.find(key);
   if (it == h->graphs.end()) {
     // First use: time one evaluation with plain launches, then capture + instantiate and time a

@@ -386,25 +386,32 @@ __global__ __launch_bounds__(vb::NT_B, 2) void gemm_f64_kernel_b(GemmParams p) {
 
   const double alpha = p.alpha, beta = p.beta;
   double* cbase = C + (long)(i0 + wr * 64 + kq) * p.ldc + j0 + wc * 64 + l15;
-#pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    if (beta != 0.0) {
-      double4_t cv[4];
+  if (beta != 0.0) {
+    // read-modify-write in four row groups, the next group's loads in flight while this one is stored
+    double4_t cv[2][4];
+    auto load_group = [&](int set, int a) {
 #pragma unroll
       for (int b = 0; b < 4; ++b)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) cv[b][r] = cbase[(long)(16 * a + 4 * r) * p.ldc + 16 * b];
+        for (int r = 0; r < 4; ++r) cv[set][b][r] = cbase[(long)(16 * a + 4 * r) * p.ldc + 16 * b];
+    };
+    load_group(0, 0);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      if (a + 1 < 4) load_group((a + 1) & 1, a + 1);
 #pragma unroll
       for (int b = 0; b < 4; ++b)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          cbase[(long)(16 * a + 4 * r) * p.ldc + 16 * b] = alpha * acc[a][b][r] + beta * cv[b][r];
-    } else {
+          cbase[(long)(16 * a + 4 * r) * p.ldc + 16 * b] = alpha * acc[a][b][r] + beta * cv[a & 1][b][r];
+    }
+  } else {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int b = 0; b < 4; ++b)
 #pragma unroll
         for (int r = 0; r < 4; ++r) cbase[(long)(16 * a + 4 * r) * p.ldc + 16 * b] = alpha * acc[a][b][r];
-    }
   }
 }
 

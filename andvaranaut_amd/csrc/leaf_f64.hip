@@ -311,41 +311,88 @@ __global__ __launch_bounds__(256, 1) void potrf_leaf128_kernel(double* __restric
 
 // X * L^T = B, in place on B (m x 128, leading dimension ldb, m multiple of 64).
 // One wave per 16 rows; tiles kept transposed: T_j[r] = B[row0 + (l&15)][16j + 4r + (l>>4)].
-// The L fragments (MFMA A operands) are read straight from L2 -- no LDS, so strip workgroups can
-// share CUs with GEMM workgroups of the concurrent trailing update -- one block column ahead.
+// The 28 sub-diagonal 16x16 tiles of L and the 8 inverse diagonal blocks are staged once per
+// workgroup in LDS in MFMA-fragment order (tile, k4-step, lane), so every A-operand read is one
+// conflict-free ds_read_b64 of 64 consecutive doubles.  72 KB: a strip workgroup can share a CU with
+// one GEMM workgroup of the concurrent trailing update.
+constexpr int STRIP_TILES = 36;  // 28 sub-diagonal tiles of L + 8 diagonal inverses
+__device__ __forceinline__ int strip_tile(int i, int j) { return i * (i - 1) / 2 + j; }  // i > j
+
 __global__ __launch_bounds__(256) void trsm_strip128_kernel(const double* __restrict__ Lblk, long lda,
                                                              const double* __restrict__ dinv,
                                                              double* __restrict__ B, long ldb, long strideL,
                                                              long strideB) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* Lt = smem;             // [28][4][64]
+  double* Dt = smem + 28 * 256;  // [8][4][64]
   Lblk += (long)blockIdx.y * strideL;
   dinv += (long)blockIdx.y * 2048;
   B += (long)blockIdx.y * strideB;
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
   const int n = lane & 15, q = lane >> 4;
+#ifdef LEAF_STAMPS
+  unsigned long long t_prev = 0;
+  if (threadIdx.x == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory");
+#endif
   double* Brow = B + ((long)blockIdx.x * 64 + wave * 16 + n) * ldb;
   double4_t T[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j)
 #pragma unroll
     for (int r = 0; r < 4; ++r) T[j][r] = Brow[16 * j + 4 * r + q];
-  // fragment (i, j, s): L[16i + (l&15)][16j + 4s + (l>>4)]
-  const double* Lfrag = Lblk + (long)n * lda + q;
+  // stage L tiles: item = (tile, row, column quad) -> 4 doubles
+  {
+    typedef double double2_t __attribute__((ext_vector_type(2)));
+    // tile row ti (1..7) holds tiles ti(ti-1)/2 .. ; 7 items per thread, all loads issued before the stores
+    double2_t v0[7], v1[7];
+#pragma unroll
+    for (int u = 0; u < 7; ++u) {
+      const int it = tid + 256 * u;
+      const int tile = it >> 6, rr = (it >> 2) & 15, cq = it & 3;
+      const int ti = (tile >= 21) ? 7 : (tile >= 15) ? 6 : (tile >= 10) ? 5 : (tile >= 6) ? 4 : (tile >= 3) ? 3 : (tile >= 1) ? 2 : 1;
+      const int tj = tile - ti * (ti - 1) / 2;
+      const double* src = Lblk + (long)(16 * ti + rr) * lda + 16 * tj + 4 * cq;
+      v0[u] = *reinterpret_cast<const double2_t*>(src);
+      v1[u] = *reinterpret_cast<const double2_t*>(src + 2);
+    }
+#pragma unroll
+    for (int u = 0; u < 7; ++u) {
+      const int it = tid + 256 * u;
+      const int tile = it >> 6, rr = (it >> 2) & 15, cq = it & 3;
+      double* dst = Lt + tile * 256 + cq * 64 + rr;  // + 16*q
+      dst[0] = v0[u].x; dst[16] = v0[u].y; dst[32] = v1[u].x; dst[48] = v1[u].y;
+    }
+    for (int it = tid; it < 8 * 64; it += 256) {
+      const int tile = it >> 6, rr = (it >> 2) & 15, cq = it & 3;
+      const double* src = dinv + tile * 256 + rr * 16 + 4 * cq;
+      const double2_t v0 = *reinterpret_cast<const double2_t*>(src);
+      const double2_t v1 = *reinterpret_cast<const double2_t*>(src + 2);
+      double* dst = Dt + tile * 256 + cq * 64 + rr;
+      dst[0] = v0.x; dst[16] = v0.y; dst[32] = v1.x; dst[48] = v1.y;
+    }
+  }
+  __syncthreads();
+#ifdef LEAF_STAMPS
+  if (blockIdx.x == 0) LEAF_STAMP(6);
+#endif
   double4_t La[2][7];  // double buffer over block columns j: La[j&1][i-j-1][s]
   double4_t Dj[2];
   auto load_col = [&](int set, int j) {
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) Dj[set][s4] = dinv[j * SB * SB + n * SB + 4 * s4 + q];
+    for (int s4 = 0; s4 < 4; ++s4) Dj[set][s4] = Dt[j * 256 + s4 * 64 + lane];
 #pragma unroll
     for (int i = j + 1; i < 8; ++i)
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) La[set][i - j - 1][s4] = Lfrag[(long)(16 * i) * lda + 16 * j + 4 * s4];
+      for (int s4 = 0; s4 < 4; ++s4) La[set][i - j - 1][s4] = Lt[strip_tile(i, j) * 256 + s4 * 64 + lane];
   };
   load_col(0, 0);
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int cur = j & 1;
     if (j + 1 < 8) load_col(cur ^ 1, j + 1);
+    __builtin_amdgcn_sched_barrier(0);  // keep the next column's reads ahead of this column's MFMAs
     // X_j = Dinv_j * T_j
     double4_t X = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -358,6 +405,9 @@ __global__ __launch_bounds__(256) void trsm_strip128_kernel(const double* __rest
       for (int s4 = 0; s4 < 4; ++s4)
         T[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(La[cur][i - j - 1][s4], Xn[s4], T[i], 0, 0, 0);
   }
+#ifdef LEAF_STAMPS
+  if (blockIdx.x == 0) LEAF_STAMP(7);
+#endif
 #pragma unroll
   for (int j = 0; j < 8; ++j)
 #pragma unroll
@@ -365,12 +415,14 @@ __global__ __launch_bounds__(256) void trsm_strip128_kernel(const double* __rest
 }
 
 constexpr size_t LEAF_LDS_BYTES = sizeof(double) * (LEAF_ELEMS + SB * SB + LEAF);
-constexpr size_t STRIP_LDS_BYTES = 0;
+constexpr size_t STRIP_LDS_BYTES = sizeof(double) * STRIP_TILES * 256;
 
 hipError_t leaf_enable_lds() {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_leaf128_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAF_LDS_BYTES);
-  return e;
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(trsm_strip128_kernel),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)STRIP_LDS_BYTES);
 }
 
 hipError_t launch_potrf_leaf128(double* Ablk, long lda, double* dinv, int col0, int* info, hipStream_t stream) {

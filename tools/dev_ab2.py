@@ -1,5 +1,5 @@
-"""Interleaved A/B of Cholesky options in one process (same box, same clocks)."""
-import sys, time, itertools
+"""Interleaved A/B of super-panel width schedules."""
+import sys, time
 import numpy as np
 sys.path.insert(0, ".")
 from andvaranaut_amd import MiGP
@@ -9,15 +9,16 @@ d = 16
 X, y = orc.synth_problem(N, d, seed=0)
 theta = orc.synth_theta(d)
 gp = MiGP(X, y, "Matern52", need_grad=False)
-gp.lml(theta)
-configs = [(la, var, w, g) for la in (1,) for var in (1,) for w in (0, 4, 8) for g in (0, 1)]
+ref = gp.lml(theta)
+configs = [(72, 0, 0), (72, 48, 0), (72, 48, 24), (72, 32, 16), (72, 64, 32), (200, 48, 24), (72, 40, 0), (72, 24, 8)]
 res = {c: [] for c in configs}
 for rnd in range(3):
     for c in configs:
-        gp.set_option(0, c[0]); gp.set_option(1, c[1]); gp.set_option(2, c[2]); gp.set_option(3, c[3])
-        gp.lml(theta)
+        for i in range(3): gp.set_option(4 + i, c[i])
+        v = gp.lml(theta)
+        assert abs(v - ref) < 1e-9 * abs(ref), (v, ref)
         t0 = time.perf_counter()
         for _ in range(3): gp.lml(theta)
         res[c].append((time.perf_counter() - t0) / 3 * 1e3)
 for c in configs:
-    print(f"lookahead={c[0]} variant={'AB'[c[1]]} W={c[2]} graph={c[3]}: median {np.median(res[c]):.2f} ms  min {min(res[c]):.2f}")
+    print(f"thresholds {c}: median {np.median(res[c]):.2f} ms  min {min(res[c]):.2f}")

@@ -55,12 +55,26 @@ def cpu_baseline(N, d, kernel, budget_s=25.0):
     from oracle import gp_oracle as orc
     import scipy.linalg as sla
 
+    # BLAS threads = the cores this process may actually run on (the GPU box gives a CPU share that is
+    # smaller than the machine; oversubscribing OpenBLAS makes dpotrf several times slower)
     try:
-        from threadpoolctl import threadpool_info
-
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+        ncpu = len(os.sched_getaffinity(0))
     except Exception:
-        threads = os.cpu_count() or 1
+        ncpu = os.cpu_count() or 1
+    try:  # cgroup v2 CPU quota, e.g. "1600000 100000" = 16 cores
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            ncpu = max(1, min(ncpu, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    ncpu = min(ncpu, 16)  # a one-GPU box's CPU share (more OpenBLAS threads than cores only slows dpotrf down)
+    try:
+        import threadpoolctl
+
+        threadpoolctl.threadpool_limits(limits=ncpu)
+        threads = min(ncpu, max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] + [1]))
+    except Exception:
+        threads = ncpu
     Ns = 4096
     X, y = orc.synth_problem(Ns, d, seed=0)
     theta = orc.synth_theta(d)
@@ -98,6 +112,7 @@ def main():
     ap.add_argument("--panel-tiles", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-steps", type=int, default=3)
+    ap.add_argument("--no-lookahead", action="store_true", help="disable the look-ahead stream everywhere (profiling aid)")
     args = ap.parse_args()
 
     import torch
@@ -118,6 +133,8 @@ def main():
     X, y = synth_problem(N, d, seed=0)
     gp = MiGP(X, y, args.kernel, device=local_rank, panel_tiles=args.panel_tiles, need_grad=False)
     thetas = theta_sequence(d, args.warmup + args.steps, seed=rank)
+    if args.no_lookahead:
+        gp.set_option(0, 0)
 
     for i in range(args.warmup):
         gp.lml(thetas[i])
@@ -153,7 +170,7 @@ def main():
             for k in acc:
                 acc[k] += tm[k]
         gp.set_profiling(0)
-        gp.set_option(0, 1)
+        gp.set_option(0, 0 if args.no_lookahead else 1)
 
     if rank == 0:
         steps = args.steps

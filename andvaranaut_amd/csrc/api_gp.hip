@@ -22,7 +22,7 @@ struct mi_gp_handle {
   hipEvent_t ev_panel, ev_upd;
   int lookahead;
   int use_graph;
-  int w_thr[3];  // trailing sizes (tile columns) above which the super-panel is 8 / 4 / 2 tiles wide
+  int w_thr[3];  // trailing sizes (tile columns) above which the super-panel is 16 / 8 / 4 tiles wide
   std::map<int, hipGraphExec_t> graphs;  // captured evaluation DAGs, keyed by (what, options)
   mi_gp_buffers buf;
   bool have_data;
@@ -97,7 +97,7 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_upd, hipEventDisableTiming);
   h->lookahead = 1;
   h->use_graph = 1;
-  h->w_thr[0] = 72; h->w_thr[1] = 0; h->w_thr[2] = 0;
+  h->w_thr[0] = 1 << 20; h->w_thr[1] = 72; h->w_thr[2] = 0;
   if (e == hipSuccess) e = hipMalloc(&h->theta_dev, sizeof(double) * h->ntheta);
   if (e == hipSuccess) e = hipMalloc(&h->out_dev, sizeof(double) * 16);
   if (e == hipSuccess) e = hipMalloc(&h->dinv_dev, sizeof(double) * 2048 * (size_t)h->ntc);
@@ -248,7 +248,7 @@ static hipError_t chol_panel(mi_gp_handle* h, double* A, long lda, int ntr, int 
 // TFLOP/s instead of ~57 at k = 512), narrower ones once the panel chain is the critical path
 static int pick_w(const mi_gp_handle* h, int rem) {
   int W = h->cfg.panel_tiles;
-  if (W <= 0) W = (rem > h->w_thr[0]) ? 8 : (rem > h->w_thr[1]) ? 4 : (rem > h->w_thr[2]) ? 2 : 1;
+  if (W <= 0) W = (rem > h->w_thr[0]) ? 16 : (rem > h->w_thr[1]) ? 8 : (rem > h->w_thr[2]) ? 4 : 4;
   return rem < W ? rem : W;
 }
 

@@ -165,6 +165,7 @@ extern "C" int mi_gp_set_option(mi_gp_handle* h, int what, int value) {
   else if (what == 2) h->cfg.panel_tiles = value;
   else if (what == 3) h->use_graph = value ? 1 : 0;
   else if (what >= 4 && what <= 6) h->w_thr[what - 4] = value;
+  else if (what == 7) set_gemm_small_tiles(value);
   else return -1;
   return 0;
 }

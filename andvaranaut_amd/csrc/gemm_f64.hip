@@ -415,6 +415,156 @@ __global__ __launch_bounds__(vb::NT_B, 2) void gemm_f64_kernel_b(GemmParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Variant S: 64x64 output tile per 256-thread workgroup (4 waves as 2x2, 32x32 per wave) for launches
+// with too few 128x128 tiles to fill the chip (the in-panel updates of the Cholesky, a few dozen to a
+// few hundred tiles, which sit on the factorisation's critical path): 4x the workgroups, 1/4 of the
+// per-workgroup latency.  GemmParams.mt / nt are reinterpreted in 64-row tiles by the launcher.
+namespace vs {
+constexpr int TS = 64;
+constexpr int BKS = 16;
+constexpr int LDS_S = 80;  // 64 + 16: odd k rows land 16 bank-pairs away from even ones
+constexpr int OPER_S = BKS * LDS_S;
+constexpr int NQS = TS * BKS / 2 / 256;  // 2
+
+template <bool KMAJOR>
+__device__ __forceinline__ void chunk_offsets(long ld, int tid, unsigned& goff, unsigned& loff, long& gstride) {
+  if (KMAJOR) {
+    const int k = tid >> 5, xc = tid & 31;  // k = 8q + (t>>5)
+    goff = (unsigned)((k * ld + 2 * xc) * 8);
+    loff = (unsigned)((k * LDS_S + 2 * xc) * 8);
+    gstride = 8 * ld * 8;
+  } else {
+    const int xl = tid & 15, kc = (tid >> 4) & 7, xh = tid >> 7;  // x = 32q + 16*(t>>7) + (t&15)
+    goff = (unsigned)(((xh * 16 + xl) * ld + 2 * kc) * 8);
+    loff = (unsigned)(((2 * kc) * LDS_S + xh * 16 + xl) * 8);
+    gstride = 32 * ld * 8;
+  }
+}
+__device__ __forceinline__ void chunk_load(const char* __restrict__ base, unsigned goff, long gstride,
+                                           double2_t (&r)[NQS]) {
+#pragma unroll
+  for (int q = 0; q < NQS; ++q) r[q] = *reinterpret_cast<const double2_t*>(base + q * gstride + goff);
+}
+template <bool KMAJOR>
+__device__ __forceinline__ void chunk_store(char* __restrict__ lds, unsigned loff, const double2_t (&r)[NQS]) {
+#pragma unroll
+  for (int q = 0; q < NQS; ++q) {
+    if (KMAJOR) {
+      *reinterpret_cast<double2_t*>(lds + loff + q * (8 * LDS_S * 8)) = r[q];
+    } else {
+      *reinterpret_cast<double*>(lds + loff + q * (32 * 8)) = r[q].x;
+      *reinterpret_cast<double*>(lds + loff + q * (32 * 8) + LDS_S * 8) = r[q].y;
+    }
+  }
+}
+}  // namespace vs
+
+template <bool A_KMAJOR, bool B_KMAJOR>
+__global__ __launch_bounds__(256, 2) void gemm_f64_kernel_s(GemmParams p) {
+  using vs::BKS; using vs::OPER_S; using vs::NQS; using vs::LDS_S; using vs::TS;
+  __shared__ __attribute__((aligned(16))) double smem[4 * vs::OPER_S];
+  double* As = smem;
+  double* Bs = smem + 2 * OPER_S;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+
+  int ti, tj;
+  tile_from_index(p, blockIdx.x, ti, tj);
+  if (p.kmode == 2) ti = p.mt - 1 - ti;
+  const int i0 = ti * TS, j0 = tj * TS;
+  int kbeg = 0, kend = p.k;
+  if (p.kmode == 1) kbeg = j0;
+  else if (p.kmode == 2) kend = i0 + TS;
+  else if (p.kmode == 3) kbeg = i0;
+  else if (p.kmode == 4) kend = j0 + TS;
+  kbeg &= ~(BKS - 1);
+
+  const double* A = p.A + (long)blockIdx.z * p.strideA;
+  const double* B = p.B + (long)blockIdx.z * p.strideB;
+  double* C = p.C + (long)blockIdx.z * p.strideC;
+
+  double4_t acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+  const int nchunk = (kend - kbeg) / BKS;
+  unsigned gA, lA, gB, lB;
+  long sA, sB;
+  vs::chunk_offsets<A_KMAJOR>(p.lda, tid, gA, lA, sA);
+  vs::chunk_offsets<B_KMAJOR>(p.ldb, tid, gB, lB, sB);
+  const char* Ag = reinterpret_cast<const char*>(A_KMAJOR ? A + (long)kbeg * p.lda + i0 : A + (long)i0 * p.lda + kbeg);
+  const char* Bg = reinterpret_cast<const char*>(B_KMAJOR ? B + (long)kbeg * p.ldb + j0 : B + (long)j0 * p.ldb + kbeg);
+  const long stepA = (A_KMAJOR ? (long)BKS * p.lda : (long)BKS) * 8;
+  const long stepB = (B_KMAJOR ? (long)BKS * p.ldb : (long)BKS) * 8;
+  char* Asb = reinterpret_cast<char*>(As);
+  char* Bsb = reinterpret_cast<char*>(Bs);
+  double2_t ra[NQS], rb[NQS];
+  if (nchunk > 0) {
+    vs::chunk_load(Ag, gA, sA, ra);
+    vs::chunk_load(Bg, gB, sB, rb);
+    vs::chunk_store<A_KMAJOR>(Asb, lA, ra);
+    vs::chunk_store<B_KMAJOR>(Bsb, lB, rb);
+  }
+  // C tile early: these launches are latency-bound, the read hides under the whole k loop
+  const int kq = lane >> 4, l15 = lane & 15;
+  const double alpha = p.alpha, beta = p.beta;
+  double* cbase = C + (long)(i0 + wr * 32 + kq) * p.ldc + j0 + wc * 32 + l15;
+  double4_t cv[2][2];
+  if (beta != 0.0) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cv[a][b][r] = cbase[(long)(16 * a + 4 * r) * p.ldc + 16 * b];
+  }
+  __syncthreads();
+
+  const double* a_ptr = As + kq * LDS_S + wr * 32 + l15;
+  const double* b_ptr = Bs + kq * LDS_S + wc * 32 + l15;
+  for (int c = 0; c < nchunk; ++c) {
+    const int boff = (c & 1) * OPER_S;
+    const bool more = (c + 1 < nchunk);
+    if (more) {
+      Ag += stepA;
+      Bg += stepB;
+      vs::chunk_load(Ag, gA, sA, ra);
+      vs::chunk_load(Bg, gB, sB, rb);
+    }
+#pragma unroll
+    for (int kk = 0; kk < BKS / 4; ++kk) {
+      const double* ap = a_ptr + boff + kk * 4 * LDS_S;
+      const double* bp = b_ptr + boff + kk * 4 * LDS_S;
+      const double a0 = ap[0], a1 = ap[16], b0 = bp[0], b1 = bp[16];
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (more) {
+      const int noff = (boff ^ OPER_S) * 8;
+      vs::chunk_store<A_KMAJOR>(Asb + noff, lA, ra);
+      vs::chunk_store<B_KMAJOR>(Bsb + noff, lB, rb);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double v = alpha * acc[a][b][r];
+        if (beta != 0.0) v += beta * cv[a][b][r];
+        cbase[(long)(16 * a + 4 * r) * p.ldc + 16 * b] = v;
+      }
+}
+
 static int tile_count(const GemmParams& p) {
   if (!p.tri) return p.mt * p.nt;
   return p.nt * (p.nt + 1) / 2 + (p.mt - p.nt) * p.nt;
@@ -429,12 +579,26 @@ static int gemm_variant() {
   return g_variant;
 }
 
+static int g_small_tiles = 1024;
 void set_gemm_variant(int v) { g_variant = v; }
+void set_gemm_small_tiles(int v) { g_small_tiles = v; }
 int gemm_variant_get() { return gemm_variant(); }
 
 hipError_t launch_gemm_f64(const GemmParams& p, int opA_kmajor, int opB_kmajor, int batch, hipStream_t stream) {
   const int nblk = tile_count(p);
   if (nblk <= 0 || batch <= 0) return hipSuccess;
+  if (gemm_variant() == 1 && nblk * batch < g_small_tiles && p.kmode != 2) {
+    // few 128x128 tiles: cut them into 64x64 ones (same enumeration, tile units halve)
+    GemmParams q = p;
+    q.mt = 2 * p.mt;
+    q.nt = 2 * p.nt;
+    dim3 grid(tile_count(q), 1, batch), block(256);
+    if (!opA_kmajor && !opB_kmajor) gemm_f64_kernel_s<false, false><<<grid, block, 0, stream>>>(q);
+    else if (!opA_kmajor && opB_kmajor) gemm_f64_kernel_s<false, true><<<grid, block, 0, stream>>>(q);
+    else if (opA_kmajor && opB_kmajor) gemm_f64_kernel_s<true, true><<<grid, block, 0, stream>>>(q);
+    else gemm_f64_kernel_s<true, false><<<grid, block, 0, stream>>>(q);
+    return hipGetLastError();
+  }
   if (gemm_variant() == 1) {
     dim3 grid(nblk, 1, batch), block(vb::NT_B);
     const size_t lds = sizeof(double) * 4 * vb::OPER_B;

@@ -103,7 +103,8 @@ int mi_gp_timers(mi_gp_handle* h, double* out, int n);
 
 /* C = beta*C + alpha*op(A)*op(B) in fp64 on v_mfma_f64_4x4x4_4b_f64; row-major, m,n multiples of
  * 128, k multiple of 32.  transa=0: A is m x k; 1: A is k x m.  transb=0: B is k x n; 1: B is n x k.
- * tri=1 computes only tiles on/below the block diagonal; kmode restricts k per tile for triangular
+ * tri=1 computes only tiles on/below the block diagonal (the element-wise lower triangle is
+ * guaranteed, the strict upper part of diagonal blocks is unspecified); kmode restricts k per tile for triangular
  * operands (0 full, 1 k>=col-tile start, 2 k<row-tile end, 3 k>=row-tile start, 4 k<col-tile end).
  * Replaces the OpenBLAS dgemm/dsyrk calls inside LAPACK dpotrf/dtrtri/dlauum that PyTensor's
  * Cholesky Op reaches (gpmcmc.py:313; scipy.linalg.cholesky). */

@@ -33,8 +33,9 @@ A = torch.randn(m, k, dtype=torch.float64, device=dev); B = torch.randn(n, k, dt
 C = torch.zeros(m, n, dtype=torch.float64, device=dev)
 gemm(0, 1, m, n, k, 1.0, A, k, B, k, 0.0, C, n, tri=1)
 ref = A @ B.T
-mask = torch.ones(4, 4, device=dev).tril().bool().repeat_interleave(128, 0).repeat_interleave(128, 1)
-err = ((C - ref) * mask).abs().max().item(); up = (C * (~mask)).abs().max().item()
+mask = torch.ones(m, n, device=dev).tril().bool()  # tri guarantees the element-wise lower triangle
+bmask = torch.ones(4, 4, device=dev).tril().bool().repeat_interleave(128, 0).repeat_interleave(128, 1)
+err = ((C - ref) * mask).abs().max().item(); up = (C * (~bmask)).abs().max().item()
 print(f"tri NT err {err:.3e}, untouched upper {up:.1e}"); ok &= err < 1e-11 and up == 0
 # kmode 1: NN with B lower-triangular
 Bl = torch.randn(k, n, dtype=torch.float64, device=dev).tril()

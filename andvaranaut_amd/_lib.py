@@ -69,6 +69,10 @@ def load():
     lib.mi_gp_set_option.argtypes = [vp, ci, ci]
     lib.mi_gp_set_profiling.argtypes = [vp, ci]
     lib.mi_gp_timers.argtypes = [vp, dp, ci]
+    ip = ctypes.POINTER(ctypes.c_int)
+    lib.mi_gp_assemble_block.argtypes = [ci, ci, ip, ip, vp, vp, ci, vp, ci, ci, ci, vp, cl, ci, ci, ci, vp]
+    lib.mi_gp_chol_panel.argtypes = [vp, cl, ci, ci, vp, vp, ci, vp]
+    lib.mi_gp_lml_partial.argtypes = [vp, cl, vp, ci, vp, vp]
     lib.mi_gp_gemm_f64.argtypes = [ci, ci, ci, ci, ci, cd, vp, cl, vp, cl, cd, vp, cl, ci, ci, ci, cl, cl, cl, vp]
     for name in EXPORTS:
         getattr(lib, name)  # raises AttributeError if a declared symbol is missing
@@ -95,4 +99,7 @@ EXPORTS = [
     "mi_gp_set_profiling",
     "mi_gp_timers",
     "mi_gp_gemm_f64",
+    "mi_gp_assemble_block",
+    "mi_gp_chol_panel",
+    "mi_gp_lml_partial",
 ]

@@ -15,7 +15,8 @@ static bool g_lds_enabled = false;
 static int ensure_init() {
   if (!g_lds_enabled) {
     hipError_t e = gemm_f64_enable_lds();
-    if (e != hipSuccess) return fail(e, "gemm_f64_enable_lds");
+    if (e == hipSuccess) e = leaf_enable_lds();
+    if (e != hipSuccess) return fail(e, "enable_lds");
     g_lds_enabled = true;
   }
   return 0;
@@ -37,5 +38,78 @@ extern "C" int mi_gp_gemm_f64(int transa, int transb, int m, int n, int k, doubl
   // op(B) = B (k x n row-major) -> [k][x]; op(B) = B^T with B stored n x k -> [x][k]
   hipError_t e = launch_gemm_f64(p, transa ? 1 : 0, transb ? 0 : 1, batch < 1 ? 1 : batch, (hipStream_t)stream);
   if (e != hipSuccess) return fail(e, "launch_gemm_f64");
+  return 0;
+}
+
+// ---------------------------------------------------------------- distributed-matrix building blocks
+static KernSpec make_spec(int d, int nkern, const int* kernel_ids, const int* ops) {
+  KernSpec s;
+  s.nkern = nkern;
+  s.d = d;
+  for (int i = 0; i < MAX_KERN; ++i) {
+    s.kid[i] = i < nkern ? kernel_ids[i] : 0;
+    s.op[i] = i < nkern ? ops[i] : 0;
+  }
+  return s;
+}
+
+extern "C" int mi_gp_assemble_block(int d, int nkern, const int* kernel_ids, const int* ops, const double* theta_dev,
+                                    const double* Xrows_dev, int nrows, const double* Xcols_dev, int ncols,
+                                    int row0, int col0, double* K_dev, long ldk, int rows_pad, int cols_pad,
+                                    int noise_form, void* stream) {
+  if (d <= 0 || nkern <= 0 || nkern > MAX_KERN || rows_pad % 64 || cols_pad % 64 || nrows < 0 || ncols < 0) {
+    snprintf(g_err, sizeof(g_err), "mi_gp_assemble_block: bad argument");
+    return -1;
+  }
+  const KernSpec spec = make_spec(d, nkern, kernel_ids, ops);
+  hipError_t e = launch_assemble(spec, theta_dev, Xrows_dev, nrows, Xcols_dev, ncols, K_dev, ldk, rows_pad, cols_pad, 0,
+                                 noise_form, (hipStream_t)stream, row0 - col0);
+  if (e != hipSuccess) return fail(e, "assemble_block");
+  return 0;
+}
+
+// factor the w leading tile columns of a (ntr x w)-tile lower trapezoid stored at A (leading dimension
+// lda): leaf + strip + in-panel updates, everything on `stream`
+static hipError_t panel_rec(double* A, long lda, int ntr, int c0, int w, double* dinv, int* info, int col_base,
+                            hipStream_t st) {
+  hipError_t e;
+  if (w == 1) {
+    double* blk = A + (long)c0 * 128 * lda + (long)c0 * 128;
+    e = launch_potrf_leaf128(blk, lda, dinv + (size_t)c0 * 2048, col_base + c0 * 128, info, st);
+    if (e != hipSuccess) return e;
+    return launch_trsm_strip128(blk, lda, dinv + (size_t)c0 * 2048, blk + 128 * lda, lda, (ntr - c0 - 1) * 128, st);
+  }
+  const int w1 = w / 2, w2 = w - w1;
+  e = panel_rec(A, lda, ntr, c0, w1, dinv, info, col_base, st);
+  if (e != hipSuccess) return e;
+  GemmParams p;
+  p.A = A + (long)(c0 + w1) * 128 * lda + (long)c0 * 128;
+  p.B = p.A;
+  p.C = A + (long)(c0 + w1) * 128 * lda + (long)(c0 + w1) * 128;
+  p.lda = p.ldb = p.ldc = lda;
+  p.strideA = p.strideB = p.strideC = 0;
+  p.mt = ntr - c0 - w1; p.nt = w2; p.k = w1 * 128; p.tri = 1; p.kmode = 0; p.alpha = -1.0; p.beta = 1.0;
+  e = launch_gemm_f64(p, 0, 0, 1, st);
+  if (e != hipSuccess) return e;
+  return panel_rec(A, lda, ntr, c0 + w1, w2, dinv, info, col_base, st);
+}
+
+extern "C" int mi_gp_chol_panel(double* A_dev, long lda, int row_tiles, int w_tiles, double* dinv_dev, int* info_dev,
+                                int col_base, void* stream) {
+  if (!A_dev || !dinv_dev || !info_dev || w_tiles <= 0 || row_tiles < w_tiles || (lda & 1)) {
+    snprintf(g_err, sizeof(g_err), "mi_gp_chol_panel: bad argument");
+    return -1;
+  }
+  if (int r = ensure_init()) return r;
+  hipError_t e = panel_rec(A_dev, lda, row_tiles, 0, w_tiles, dinv_dev, info_dev, col_base, (hipStream_t)stream);
+  if (e != hipSuccess) return fail(e, "chol_panel");
+  return 0;
+}
+
+// out[1] += sum log L_ii over n diagonal entries, out[2] += sum beta_i^2 (out[0] is scratch)
+extern "C" int mi_gp_lml_partial(const double* L_dev, long ld, const double* beta_dev, int n, double* out_dev,
+                                 void* stream) {
+  hipError_t e = launch_lml_reduce(L_dev, ld, beta_dev, n, out_dev, (hipStream_t)stream);
+  if (e != hipSuccess) return fail(e, "lml_partial");
   return 0;
 }

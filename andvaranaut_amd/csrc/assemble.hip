@@ -32,7 +32,8 @@ __global__ __launch_bounds__(256) void assemble_kernel(KernSpec spec, const doub
                                                        const double* __restrict__ X1, int n1,
                                                        const double* __restrict__ X2, int n2,
                                                        double* __restrict__ K, long ldk, int rows_pad,
-                                                       int cols_pad, int sym, int noise_form) {
+                                                       int cols_pad, int sym, int noise_form,
+                                                       int diag_shift) {
   __shared__ double Xi[AT * DLD];
   __shared__ double Xj[AT * DLD];
   __shared__ double n2i[AT], n2j[AT];
@@ -116,6 +117,9 @@ __global__ __launch_bounds__(256) void assemble_kernel(KernSpec spec, const doub
       }
   }
   const double sg = sqrt(gv);
+  // diagonal of the global matrix: local (gi, gj) with gi + diag_shift == gj; sym mode has shift 0,
+  // rectangular blocks of a distributed matrix pass row0 - col0, cross-covariances pass INT_MIN (none)
+  const bool diag_on = sym || diag_shift != -2147483647 - 1;
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     const int gi = i0 + ty + 16 * a;
@@ -124,8 +128,8 @@ __global__ __launch_bounds__(256) void assemble_kernel(KernSpec spec, const doub
       const int gj = j0 + tx + 16 * b;
       double v = Kacc[a][b];
       if (gi >= n1 || gj >= n2) {
-        v = (sym && gi == gj) ? 1.0 : 0.0;
-      } else if (sym && gi == gj) {
+        v = (diag_on && gi + diag_shift == gj) ? 1.0 : 0.0;
+      } else if (diag_on && gi + diag_shift == gj) {
         if (noise_form == 0) { v += sg * sg; v += jitter; }       // Marginal._build_marginal_likelihood
         else if (noise_form == 1) { v += jitter; v += sg * sg; }  // Marginal._build_conditional
         else { v += jitter + gv; }                                // gpmcmc.py:312 explicit form
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(1024) void lml_reduce_kernel(const double* __restri
 
 hipError_t launch_assemble(const KernSpec& spec, const double* theta, const double* X1, int n1, const double* X2,
                            int n2, double* K, long ldk, int rows_pad, int cols_pad, int sym, int noise_form,
-                           hipStream_t stream) {
+                           hipStream_t stream, int diag_shift) {
   int nblk;
   if (sym) {
     const int nt = rows_pad / AT;
@@ -185,7 +189,8 @@ hipError_t launch_assemble(const KernSpec& spec, const double* theta, const doub
   } else {
     nblk = (rows_pad / AT) * (cols_pad / AT);
   }
-  assemble_kernel<<<nblk, 256, 0, stream>>>(spec, theta, X1, n1, X2, n2, K, ldk, rows_pad, cols_pad, sym, noise_form);
+  assemble_kernel<<<nblk, 256, 0, stream>>>(spec, theta, X1, n1, X2, n2, K, ldk, rows_pad, cols_pad, sym, noise_form,
+                                            sym ? 0 : diag_shift);
   return hipGetLastError();
 }
 

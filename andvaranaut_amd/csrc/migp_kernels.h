@@ -51,7 +51,9 @@ struct KernSpec {
 // sym=0: full K(X1,X2), zeros in the padding.  noise_form: 0 marginal, 1 conditional, 2 explicit.
 hipError_t launch_assemble(const KernSpec& spec, const double* theta, const double* X1, int n1, const double* X2,
                            int n2, double* K, long ldk, int rows_pad, int cols_pad, int sym, int noise_form,
-                           hipStream_t stream);
+                           hipStream_t stream, int diag_shift = -2147483647 - 1);
+// diag_shift (sym=0 only): local element (i, j) is on the global diagonal when i + diag_shift == j
+// (rectangular blocks of a distributed covariance); the default means "no diagonal" (cross-covariance).
 hipError_t launch_set_yrows(double* K, long ldk, int row0, int cols_pad, const double* y, int n, hipStream_t stream);
 hipError_t launch_lml_reduce(const double* L, long ld, const double* beta, int n, double* out, hipStream_t stream);
 

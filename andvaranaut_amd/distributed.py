@@ -1,0 +1,174 @@
+"""One log-marginal-likelihood evaluation sharded over the GPUs of a node (second
+row; BASELINE config 4): 1-D block-cyclic distribution of 512-column super-panels of the covariance
+over the ranks, right-looking Cholesky in which the owner factors a panel and broadcasts it
+(torch.distributed: RCCL over xGMI with backend "nccl") and every rank updates the panels it owns.
+One look-ahead step: the owner of the next panel updates and factors it first and its broadcast is
+posted before the bulk updates, so the transfer overlaps them.
+
+Only the exchange step is a collective (one broadcast per panel, two scalars all-reduced at the
+end); assembly is local (X is replicated, 8*N*d bytes).  All arithmetic runs in the same HIP kernels
+as the single-GPU path, reached through the block-level C-ABI entry points
+(mi_gp_assemble_block, mi_gp_chol_panel, mi_gp_gemm_f64, mi_gp_lml_partial)."""
+import ctypes
+import math
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from .backend import parse_kernel
+
+PW_TILES = 4  # super-panel width in 128-column tiles
+
+
+class DistGP:
+    """A GP data set whose covariance is column-panel sharded over the ranks of the default process
+    group (or a single process when torch.distributed is not initialised)."""
+
+    def __init__(self, X, y, kernel="RBF", device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("DistGP needs ROCm GPUs: the GP hot path has no CPU implementation")
+        self.lib = _lib.load()
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        y = np.ascontiguousarray(np.asarray(y, dtype=np.float64).reshape(-1))
+        self.n, self.d = X.shape
+        self.kerns, self.ops = parse_kernel(kernel)
+        self.nkern = len(self.kerns)
+        self.dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self.np_ = (self.n + 127) // 128 * 128
+        self.ntc = self.np_ // 128
+        self.npan = (self.ntc + PW_TILES - 1) // PW_TILES
+        self.pw = PW_TILES * 128
+        self.own = [j for j in range(self.npan) if j % self.world == self.rank]
+        self.local_index = {j: i for i, j in enumerate(self.own)}
+        self.ntheta = self.nkern * self.d + 2 * self.nkern + 2
+        rows = self.np_ + 128  # + the y^T row block (forward solve folded into the factorisation)
+        self.ld = max(len(self.own), 1) * self.pw + 16
+        self.ldbuf = self.pw + 16
+        with torch.cuda.device(self.dev):
+            self.X_t = torch.from_numpy(X).to(self.dev)
+            self.y_t = torch.from_numpy(y).to(self.dev)
+            self.K = torch.zeros((rows, self.ld), dtype=torch.float64, device=self.dev)
+            self.P = [torch.zeros((rows, self.ldbuf), dtype=torch.float64, device=self.dev) for _ in range(2)]
+            self.theta_t = torch.zeros(self.ntheta, dtype=torch.float64, device=self.dev)
+            self.dinv = torch.zeros(PW_TILES * 2048, dtype=torch.float64, device=self.dev)
+            self.info = torch.zeros(4, dtype=torch.int32, device=self.dev)
+            self.out = torch.zeros(16, dtype=torch.float64, device=self.dev)
+        self.kids = (ctypes.c_int * _lib.MAX_KERN)(*[_lib.KERNEL_IDS[k] for k in self.kerns] + [0] * (_lib.MAX_KERN - self.nkern))
+        self.opids = (ctypes.c_int * _lib.MAX_KERN)(*[_lib.OP_IDS[o] for o in self.ops] + [0] * (_lib.MAX_KERN - len(self.ops)))
+
+    # ------------------------------------------------------------------ helpers
+    def _w(self, j):
+        return min(PW_TILES, self.ntc - j * PW_TILES)
+
+    def _check(self, r, what):
+        if r != 0:
+            raise RuntimeError(f"{what} failed ({r}): {self.lib.mi_gp_last_global_error().decode()}")
+
+    def _ptr(self, t, row, col):
+        return t.data_ptr() + 8 * (row * t.stride(0) + col)
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def _assemble(self, j, noise_form):
+        li, w = self.local_index[j], self._w(j)
+        r0 = c0 = j * self.pw
+        nrows, ncols = max(0, self.n - r0), max(0, min(self.n - c0, w * 128))
+        self._check(self.lib.mi_gp_assemble_block(
+            self.d, self.nkern, self.kids, self.opids, self.theta_t.data_ptr(),
+            self.X_t.data_ptr() + 8 * r0 * self.d, nrows, self.X_t.data_ptr() + 8 * c0 * self.d, ncols, r0, c0,
+            self._ptr(self.K, r0, li * self.pw), self.ld, self.np_ - r0, w * 128, noise_form, self._stream()),
+            "mi_gp_assemble_block")
+        yr = self.K[self.np_:, li * self.pw: li * self.pw + w * 128]
+        yr.zero_()
+        if ncols > 0:
+            yr[0, :ncols] = self.y_t[c0: c0 + ncols]
+
+    def _factor(self, j):
+        li, w = self.local_index[j], self._w(j)
+        r0 = j * self.pw
+        self._check(self.lib.mi_gp_chol_panel(self._ptr(self.K, r0, li * self.pw), self.ld, (self.np_ + 128 - r0) // 128, w,
+                                              self.dinv.data_ptr(), self.info.data_ptr(), r0, self._stream()),
+                    "mi_gp_chol_panel")
+
+    def _update(self, jt, j, buf):
+        """panel jt (owned) -= P_j[rows >= jt] P_j[rows of jt]^T, lower trapezoid only."""
+        li, wt, wj = self.local_index[jt], self._w(jt), self._w(j)
+        rt = jt * self.pw
+        m = self.np_ + 128 - rt
+        off = rt - j * self.pw  # row of panel jt's diagonal block inside the broadcast buffer
+        a_ptr = self._ptr(buf, off, 0)
+        self._check(self.lib.mi_gp_gemm_f64(0, 1, m, wt * 128, wj * 128, -1.0, a_ptr, self.ldbuf, a_ptr, self.ldbuf, 1.0,
+                                            self._ptr(self.K, rt, li * self.pw), self.ld, 1, 0, 1, 0, 0, 0, self._stream()),
+                    "mi_gp_gemm_f64")
+
+    def _stage(self, j, buf):
+        li, w = self.local_index[j], self._w(j)
+        r0 = j * self.pw
+        rows = self.np_ + 128 - r0
+        buf[:rows, : w * 128].copy_(self.K[r0:, li * self.pw: li * self.pw + w * 128])
+
+    # ------------------------------------------------------------------ evaluation
+    def lml(self, theta, noise_form=0):
+        """LML at natural-scale theta (C-ABI layout); -inf if the covariance is not positive definite."""
+        theta = np.ascontiguousarray(theta, dtype=np.float64)
+        if theta.shape != (self.ntheta,):
+            raise ValueError(f"theta must have {self.ntheta} entries")
+        with torch.cuda.device(self.dev):
+            self.theta_t.copy_(torch.from_numpy(theta))
+            self.info.fill_(0x7F7F7F7F)
+            for j in self.own:
+                self._assemble(j, noise_form)
+            owner = lambda j: j % self.world  # noqa: E731
+            if owner(0) == self.rank:
+                self._factor(0)
+                self._stage(0, self.P[0])
+            work = self._bcast(0)
+            for j in range(self.npan):
+                buf = self.P[j % 2]
+                if work is not None:
+                    work.wait()
+                jn = j + 1
+                work = None
+                if jn < self.npan:
+                    if owner(jn) == self.rank:
+                        self._update(jn, j, buf)
+                        self._factor(jn)
+                        self._stage(jn, self.P[jn % 2])
+                    work = self._bcast(jn)  # posted before the bulk updates so that it overlaps them
+                for jt in self.own:
+                    if jt > jn:
+                        self._update(jt, j, buf)
+            # local pieces of sum log L_ii and |beta|^2, then one small all-reduce
+            acc = torch.zeros(3, dtype=torch.float64, device=self.dev)
+            for j in self.own:
+                li, w = self.local_index[j], self._w(j)
+                c0 = j * self.pw
+                nv = max(0, min(self.n - c0, w * 128))
+                if nv == 0:
+                    continue
+                self._check(self.lib.mi_gp_lml_partial(self._ptr(self.K, c0, li * self.pw), self.ld,
+                                                       self._ptr(self.K, self.np_, li * self.pw), nv, self.out.data_ptr(),
+                                                       self._stream()), "mi_gp_lml_partial")
+                acc[:2] += self.out[1:3]
+            info = self.info[:1].clone()
+            if self.world > 1:
+                dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+                dist.all_reduce(info, op=dist.ReduceOp.MIN)
+            logdet, quad = acc[0].item(), acc[1].item()
+            self.info_value = int(info.item())
+        if self.info_value != 0x7F7F7F7F:
+            return -math.inf
+        self.logdet, self.quad = logdet, quad
+        return -0.5 * self.n * math.log(2.0 * math.pi) - 0.5 * quad - logdet
+
+    def _bcast(self, j):
+        if self.world == 1:
+            return None
+        rows = self.np_ + 128 - j * self.pw
+        view = self.P[j % 2][:rows]  # contiguous leading rows of the panel buffer
+        return dist.broadcast(view, src=j % self.world, async_op=True)

@@ -112,6 +112,23 @@ int mi_gp_gemm_f64(int transa, int transb, int m, int n, int k, double alpha, co
                    const double* B_dev, long ldb, double beta, double* C_dev, long ldc, int tri, int kmode,
                    int batch, long strideA, long strideB, long strideC, void* hip_stream);
 
+/* K(Xrows, Xcols) for one rectangular block of a (distributed) covariance: rows row0.. and columns
+ * col0.. of the global matrix; noise + jitter go on the global diagonal, identity in the padding
+ * (rows >= nrows / columns >= ncols of the padded block).  Same kernel as the single-GPU assembly
+ * (gpmcmc.py:282-312). */
+int mi_gp_assemble_block(int d, int nkern, const int* kernel_ids, const int* ops, const double* theta_dev,
+                         const double* Xrows_dev, int nrows, const double* Xcols_dev, int ncols, int row0, int col0,
+                         double* K_dev, long ldk, int rows_pad, int cols_pad, int noise_form, void* hip_stream);
+
+/* Factor the w_tiles leading 128-column tiles of a (row_tiles x w_tiles)-tile lower trapezoid in place:
+ * diagonal leaves, strip solves of all rows below, in-panel updates.  dinv_dev: w_tiles*2048 doubles of
+ * scratch; *info_dev receives atomicMin(col_base + bad pivot index + 1).  LAPACK dpotrf panel step. */
+int mi_gp_chol_panel(double* A_dev, long lda, int row_tiles, int w_tiles, double* dinv_dev, int* info_dev,
+                     int col_base, void* hip_stream);
+
+/* out_dev[1] = sum_i log L[i][i], out_dev[2] = sum_i beta[i]^2 over n entries (one workgroup). */
+int mi_gp_lml_partial(const double* L_dev, long ld, const double* beta_dev, int n, double* out_dev, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

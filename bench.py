@@ -101,6 +101,45 @@ def cpu_baseline(N, d, kernel, budget_s=25.0):
     }
 
 
+def sharded_main(args, X, y, rank, world, dev):
+    """Strong-scaling variant: every rank owns a block-cyclic share of the 512-column panels of ONE
+    covariance (andvaranaut_amd/distributed.py); one broadcast per panel over RCCL."""
+    import torch
+    import torch.distributed as dist
+
+    from andvaranaut_amd.distributed import DistGP
+
+    N, d = X.shape
+    gp = DistGP(X, y, args.kernel, device=dev.index)
+    thetas = theta_sequence(d, args.warmup + args.steps, seed=0)  # same theta on every rank
+    for i in range(args.warmup):
+        gp.lml(thetas[i])
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    vals = [gp.lml(thetas[args.warmup + i]) for i in range(args.steps)]
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert all(np.isfinite(v) for v in vals)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "gp_lml_evals_per_s", "value": args.steps / elapsed, "unit": "evals/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.kernel} GP LML eval, ONE covariance N={N} d={d} sharded over {world} GPU(s)",
+                       "N": N, "d": d, "kernel": args.kernel, "parallelism": f"column-panel block-cyclic x{world}"},
+            "cholesky_tflops_whole_eval": (N ** 3 / 3.0) / (elapsed / args.steps) * 1e-12}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -112,6 +151,7 @@ def main():
     ap.add_argument("--panel-tiles", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-steps", type=int, default=3)
+    ap.add_argument("--sharded", action="store_true", help="ONE covariance sharded over all ranks (strong scaling, panel broadcast)")
     ap.add_argument("--no-lookahead", action="store_true", help="disable the look-ahead stream everywhere (profiling aid)")
     args = ap.parse_args()
 
@@ -131,6 +171,8 @@ def main():
 
     N, d = args.n, args.d
     X, y = synth_problem(N, d, seed=0)
+    if args.sharded:
+        return sharded_main(args, X, y, rank, world, dev)
     gp = MiGP(X, y, args.kernel, device=local_rank, panel_tiles=args.panel_tiles, need_grad=False)
     thetas = theta_sequence(d, args.warmup + args.steps, seed=rank)
     if args.no_lookahead:

@@ -158,10 +158,10 @@ class MiGP:
         self.lib.mi_gp_set_profiling(self.h, int(level))
 
     def timers(self):
-        out = (ctypes.c_double * 10)()
-        self.lib.mi_gp_timers(self.h, out, 10)
+        out = (ctypes.c_double * 13)()
+        self.lib.mi_gp_timers(self.h, out, 13)
         keys = ["assemble_ms", "cholesky_ms", "reduce_ms", "total_ms", "gemm_ms", "gemm_flops", "gemm_launches",
-                "trtri_ms", "lauum_ms", "contract_ms"]
+                "trtri_ms", "lauum_ms", "contract_ms", "gemm_b_ms", "gemm_b_flops", "gemm_b_launches"]
         return dict(zip(keys, list(out)))
 
     def close(self):

@@ -42,10 +42,13 @@ struct mi_gp_handle {
   int prof_level;
   hipEvent_t ev[8];
   std::vector<hipEvent_t> gemm_ev;  // pairs
+  std::vector<char> gemm_ev_big;    // per pair: 1 if the 128x128-tile kernel ran
+  std::vector<double> gemm_ev_flops;
   size_t gemm_ev_used;
   double gemm_flops_acc;
   double t_assemble_ms, t_chol_ms, t_reduce_ms, t_gemm_ms, t_total_ms, gemm_flops, n_gemm;
   double t_trtri_ms, t_lauum_ms, t_contract_ms;
+  double t_gemm_big_ms, gemm_big_flops, n_gemm_big;  // the 128x128-tile kernel only
   bool factored;
   char err[256];
 };
@@ -84,6 +87,7 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   h->have_data = false;
   h->factored = false;
   h->t_trtri_ms = h->t_lauum_ms = h->t_contract_ms = 0.0;
+  h->t_gemm_big_ms = h->gemm_big_flops = h->n_gemm_big = 0.0;
   h->prof_level = 0;
   h->gemm_ev_used = 0;
   hipError_t e = hipSetDevice(h->device);
@@ -191,6 +195,10 @@ static hipError_t prof_gemm(mi_gp_handle* h, const GemmParams& p, int ak, int bk
     hipEventRecord(h->gemm_ev[h->gemm_ev_used], st);
     hipError_t r = launch_gemm_f64(p, ak, bk, batch, st);
     hipEventRecord(h->gemm_ev[h->gemm_ev_used + 1], st);
+    const size_t pair = h->gemm_ev_used / 2;
+    if (h->gemm_ev_big.size() <= pair) { h->gemm_ev_big.resize(pair + 64); h->gemm_ev_flops.resize(pair + 64); }
+    h->gemm_ev_big[pair] = gemm_uses_small_tiles(p, batch) ? 0 : 1;
+    h->gemm_ev_flops[pair] = flops;
     h->gemm_ev_used += 2;
     h->gemm_flops_acc += flops;
     return r;
@@ -396,12 +404,16 @@ static int factor_internal(mi_gp_handle* h, const double* theta, int what) {
     hipEventElapsedTime(&ms, h->ev[1], h->ev[2]); h->t_chol_ms = ms;
     hipEventElapsedTime(&ms, h->ev[2], h->ev[3]); h->t_reduce_ms = ms;
     hipEventElapsedTime(&ms, h->ev[0], h->ev[3]); h->t_total_ms = ms;
-    double g = 0.0;
+    double g = 0.0, gb = 0.0, fb = 0.0, nb = 0.0;
     for (size_t i = 0; i + 1 < h->gemm_ev_used; i += 2) {
       hipEventElapsedTime(&ms, h->gemm_ev[i], h->gemm_ev[i + 1]);
       g += ms;
+      if (h->gemm_ev_big[i / 2]) { gb += ms; fb += h->gemm_ev_flops[i / 2]; nb += 1.0; }
     }
     h->t_gemm_ms = g;
+    h->t_gemm_big_ms = gb;
+    h->gemm_big_flops = fb;
+    h->n_gemm_big = nb;
     h->gemm_flops = h->gemm_flops_acc;
     h->n_gemm = (double)(h->gemm_ev_used / 2);
     if (what == 2) {
@@ -432,12 +444,13 @@ extern "C" int mi_gp_lml_parts(mi_gp_handle* h, double* logdet, double* quad) {
 }
 
 // out: [assemble_ms, chol_ms, reduce_ms, total_ms, gemm_ms, gemm_flops, n_gemm_launches,
-//       trtri_ms, lauum_ms, contract_ms]
+//       trtri_ms, lauum_ms, contract_ms, gemm_b_ms, gemm_b_flops, n_gemm_b_launches]
 extern "C" int mi_gp_timers(mi_gp_handle* h, double* out, int n) {
   if (!h || !out) return -1;
-  const double v[10] = {h->t_assemble_ms, h->t_chol_ms, h->t_reduce_ms, h->t_total_ms, h->t_gemm_ms, h->gemm_flops,
-                        h->n_gemm, h->t_trtri_ms, h->t_lauum_ms, h->t_contract_ms};
-  for (int i = 0; i < n && i < 10; ++i) out[i] = v[i];
+  const double v[13] = {h->t_assemble_ms, h->t_chol_ms, h->t_reduce_ms, h->t_total_ms, h->t_gemm_ms, h->gemm_flops,
+                        h->n_gemm, h->t_trtri_ms, h->t_lauum_ms, h->t_contract_ms, h->t_gemm_big_ms,
+                        h->gemm_big_flops, h->n_gemm_big};
+  for (int i = 0; i < n && i < 13; ++i) out[i] = v[i];
   return 0;
 }
 

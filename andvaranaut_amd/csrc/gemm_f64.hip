@@ -582,12 +582,16 @@ static int gemm_variant() {
 static int g_small_tiles = 1024;
 void set_gemm_variant(int v) { g_variant = v; }
 void set_gemm_small_tiles(int v) { g_small_tiles = v; }
+static int tile_count(const GemmParams& p);
+bool gemm_uses_small_tiles(const GemmParams& p, int batch) {
+  return gemm_variant() == 1 && tile_count(p) * batch < g_small_tiles && p.kmode != 2;
+}
 int gemm_variant_get() { return gemm_variant(); }
 
 hipError_t launch_gemm_f64(const GemmParams& p, int opA_kmajor, int opB_kmajor, int batch, hipStream_t stream) {
   const int nblk = tile_count(p);
   if (nblk <= 0 || batch <= 0) return hipSuccess;
-  if (gemm_variant() == 1 && nblk * batch < g_small_tiles && p.kmode != 2) {
+  if (gemm_uses_small_tiles(p, batch)) {
     // few 128x128 tiles: cut them into 64x64 ones (same enumeration, tile units halve)
     GemmParams q = p;
     q.mt = 2 * p.mt;

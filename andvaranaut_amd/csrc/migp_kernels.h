@@ -24,7 +24,8 @@ hipError_t launch_gemm_f64(const GemmParams& p, int opA_kmajor, int opB_kmajor, 
 hipError_t gemm_f64_enable_lds();
 int gemm_variant_get();
 void set_gemm_variant(int v);
-void set_gemm_small_tiles(int v);  // launches with fewer 128x128 tiles than this use 64x64 tiles  // 0: 8-wave / 1 workgroup per CU, 1: 4-wave / 2 workgroups per CU (default)
+void set_gemm_small_tiles(int v);
+bool gemm_uses_small_tiles(const GemmParams& p, int batch);  // true: the 64x64-tile kernel will run  // launches with fewer 128x128 tiles than this use 64x64 tiles  // 0: 8-wave / 1 workgroup per CU, 1: 4-wave / 2 workgroups per CU (default)
 
 // ---------------------------------------------------------------- leaf_f64.hip
 hipError_t leaf_enable_lds();

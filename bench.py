@@ -201,7 +201,8 @@ def main():
     # around every phase and every GEMM launch.  Look-ahead is switched off for this pass so that
     # the dominant kernel runs alone on the chip and its launch durations are not inflated by the
     # panel kernels that overlap it in the timed region (graph replay is bypassed by profiling).
-    acc = {"assemble_ms": 0.0, "cholesky_ms": 0.0, "gemm_ms": 0.0, "gemm_flops": 0.0, "gemm_launches": 0.0, "total_ms": 0.0}
+    acc = {"assemble_ms": 0.0, "cholesky_ms": 0.0, "gemm_ms": 0.0, "gemm_flops": 0.0, "gemm_launches": 0.0, "total_ms": 0.0,
+           "gemm_b_ms": 0.0, "gemm_b_flops": 0.0, "gemm_b_launches": 0.0}
     rsteps = max(1, min(args.roofline_steps, args.steps))
     if rank == 0:
         gp.set_option(0, 0)
@@ -216,8 +217,11 @@ def main():
 
     if rank == 0:
         steps = args.steps
-        gemm_avg_ms = acc["gemm_ms"] / max(acc["gemm_launches"], 1.0)
-        achieved = acc["gemm_flops"] / (acc["gemm_ms"] * 1e-3) * 1e-12 if acc["gemm_ms"] > 0 else 0.0
+        # dominant kernel = gemm_f64_kernel_b (128x128 tiles); the 64x64-tile kernel that serves the small
+        # in-panel updates is reported next to it
+        gemm_avg_ms = acc["gemm_b_ms"] / max(acc["gemm_b_launches"], 1.0)
+        achieved = acc["gemm_b_flops"] / (acc["gemm_b_ms"] * 1e-3) * 1e-12 if acc["gemm_b_ms"] > 0 else 0.0
+        all_gemm = acc["gemm_flops"] / (acc["gemm_ms"] * 1e-3) * 1e-12 if acc["gemm_ms"] > 0 else 0.0
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "gemm_traffic.json")
         if os.path.exists(tfile):
@@ -247,7 +251,9 @@ def main():
             "roofline": {"kernel": "gemm_f64_kernel_b (SYRK trailing/panel updates, v_mfma_f64_16x16x4_f64)",
                          "bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
-                         "avg_launch_ms": gemm_avg_ms, "launches_per_step": acc["gemm_launches"] / rsteps},
+                         "avg_launch_ms": gemm_avg_ms, "launches_per_step": acc["gemm_b_launches"] / rsteps,
+                         "flop_share_of_all_gemm": acc["gemm_b_flops"] / max(acc["gemm_flops"], 1.0),
+                         "all_gemm_kernels_tflops": all_gemm, "all_gemm_launches_per_step": acc["gemm_launches"] / rsteps},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(N, d, args.kernel)

@@ -94,8 +94,9 @@ int mi_gp_set_option(mi_gp_handle* h, int what, int value);
 
 /* profiling: level 0 none, 1 per-phase HIP events, 2 additionally per-GEMM-launch HIP events */
 int mi_gp_set_profiling(mi_gp_handle* h, int level);
-/* out[0..9] = assemble_ms, cholesky_ms, reduce_ms, total_ms, gemm_ms (sum over launches),
- *             gemm_flops (algorithmic), number of gemm launches, trtri_ms, lauum_ms, contract_ms
+/* out[0..12] = assemble_ms, cholesky_ms, reduce_ms, total_ms, gemm_ms (sum over launches),
+ *             gemm_flops (algorithmic), number of gemm launches, trtri_ms, lauum_ms, contract_ms,
+ *             then the same three GEMM figures for the 128x128-tile kernel (gemm_f64_kernel_b) alone
  *             -- of the last evaluation */
 int mi_gp_timers(mi_gp_handle* h, double* out, int n);
 

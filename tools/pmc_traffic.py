@@ -9,7 +9,7 @@ def per_kernel(d, counter):
     f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
     tot, n = 0.0, 0
     for r in csv.DictReader(open(f)):
-        if "gemm_f64_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+        if "gemm_f64_kernel_b" in r["Kernel_Name"] and r["Counter_Name"] == counter:
             tot += float(r["Counter_Value"]); n += 1
     return tot, n
 
@@ -19,7 +19,7 @@ out = {
     "kernel": "gemm_f64_kernel_b", "launches": n1,
     "fetch_kib_raw_per_launch": fetch / max(n1, 1), "write_kib_per_launch": write / max(n2, 1),
     "hbm_bytes_per_launch": (2.0 * fetch / max(n1, 1) + write / max(n2, 1)) * 1024.0,
-    "note": "FETCH_SIZE doubled (gfx950 wide-read correction), WRITE_SIZE as is; average over every GEMM launch of the run",
+    "note": "FETCH_SIZE doubled (gfx950 wide-read correction), WRITE_SIZE as is; average over every gemm_f64_kernel_b launch of the run",
 }
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out))

@@ -248,6 +248,12 @@ def main():
             "roofline_pass": {"steps": rsteps, "lookahead": False,
                               "phase_ms": {"assemble": acc["assemble_ms"] / rsteps, "cholesky": acc["cholesky_ms"] / rsteps,
                                            "gemm_in_cholesky": acc["gemm_ms"] / rsteps}},
+            # K1/K2: lower-triangle 64x64 tiles written once + X read once (8*N*d): HBM-side figure the
+            # north star asks for next to the MFMA one
+            "assembly": {"kernel": "assemble_kernel", "ms": acc["assemble_ms"] / rsteps,
+                         "algorithmic_bytes": 8.0 * (N // 64) * (N // 64 + 1) / 2 * 64 * 64 + 8.0 * N * d,
+                         "achieved_GBps": (8.0 * (N // 64) * (N // 64 + 1) / 2 * 64 * 64 + 8.0 * N * d)
+                         / (acc["assemble_ms"] / rsteps * 1e-3) * 1e-9, "peak_GBps": 8000.0},
             "roofline": {"kernel": "gemm_f64_kernel_b (SYRK trailing/panel updates, v_mfma_f64_16x16x4_f64)",
                          "bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,

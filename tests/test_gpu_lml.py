@@ -134,3 +134,58 @@ def test_config4_shape_fits_one_gpu():
     assert abs(v1 - (-0.5 * N * np.log(2 * np.pi) - 0.5 * quad - logdet)) <= 1e-12 * abs(v1)
     assert gp.lml(theta) == v1
     gp.close()
+
+
+def test_four_component_kernel_and_many_dims():
+    """MI_GP_MAX_KERN components and d > 64 (three LDS chunks of the input dimension)."""
+    MiGP, orc = _mods()
+    N, d = 400, 70
+    X, y = orc.synth_problem(N, d, seed=5)
+    kernel = "RBF+Matern52*Matern32+RatQuad"
+    kerns, ops = ["RBF", "Matern52", "Matern32", "RatQuad"], ["+", "*", "+"]
+    theta = orc.synth_theta(d, nkern=4, gv=1e-3)
+    theta[:4 * d] *= 6.0  # length scales ~ sqrt(d) so the kernel is not numerically the identity
+    theta[4 * d + 4: 4 * d + 8] = [1.0, 1.0, 1.0, 2.2]  # RatQuad alpha
+    gp = MiGP(X, y, kernel)
+    val, g = gp.lml_grad(theta)
+    ref, gref = orc.lml_grad(X, y, kerns, ops, theta)
+    assert abs(val - ref) <= 1e-10 * abs(ref), (val, ref)
+    assert np.abs(g - gref).max() <= 1e-8 * np.abs(gref).max()
+    Xn = np.random.default_rng(1).random((33, d))
+    mu, var = gp.predict(theta, Xn)
+    rmu, rvar = orc.predict(X, y, Xn, kerns, ops, theta)
+    assert np.allclose(mu, rmu, rtol=1e-9, atol=1e-9) and np.allclose(var, rvar, rtol=1e-8, atol=1e-11)
+    gp.close()
+
+
+def test_handles_can_be_created_and_destroyed_repeatedly():
+    MiGP, orc = _mods()
+    import torch
+
+    X, y = orc.synth_problem(600, 3, seed=1)
+    theta = orc.synth_theta(3)
+    ref = orc.lml(X, y, ["RBF"], [], theta)
+    torch.cuda.synchronize()
+    base = torch.cuda.memory_allocated()
+    for _ in range(20):
+        gp = MiGP(X, y, "RBF")
+        assert abs(gp.lml(theta) - ref) <= 1e-10 * abs(ref)
+        gp.close()
+        del gp
+    torch.cuda.synchronize()
+    assert torch.cuda.memory_allocated() <= base + (1 << 20)
+
+
+def test_tuning_options_do_not_change_results():
+    MiGP, orc = _mods()
+    X, y = orc.synth_problem(3000, 6, seed=2)
+    theta = orc.synth_theta(6)
+    gp = MiGP(X, y, "Matern52", need_grad=False)
+    ref = gp.lml(theta)
+    for what, value in [(0, 0), (1, 0), (2, 2), (2, 8), (3, 0), (7, 0), (7, 100000)]:
+        gp.set_option(what, value)
+        v = gp.lml(theta)
+        assert abs(v - ref) <= 1e-11 * abs(ref), (what, value, v, ref)
+    for what, value in [(0, 1), (1, 1), (2, 0), (3, 1), (7, 1024)]:  # back to the defaults (1 and 7 are process-wide)
+        gp.set_option(what, value)
+    gp.close()

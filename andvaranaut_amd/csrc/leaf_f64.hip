@@ -99,6 +99,34 @@ __device__ __forceinline__ double mov_rowbcast(double src) {
   return out;
 }
 
+// broadcast lane G of every quad (4 consecutive lanes) to the quad: two 32-bit DPP moves
+template <int G>
+__device__ __forceinline__ double quad_bcast(double v) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(u & 0xffffffffu), G * 0x55, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(u >> 32), G * 0x55, 0xf, 0xf, false);
+  return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+// Forward substitution X = B L16^-T for 16 rows on one wave: lane 4*row + g owns columns g, g+4, g+8, g+12.
+template <int K>
+struct QuadSolve {
+  // lt[K][i] = L16[4i+g][K] and inv[i] = 1/L16[4i+g][4i+g] are preloaded so that no LDS latency sits on the chain
+  static __device__ __forceinline__ void run(double (&x)[4], const double (&lt)[16][4], const double (&inv)[4], int g) {
+    const double xk = quad_bcast<(K & 3)>(x[K >> 2] * inv[K >> 2]);
+    if (g == (K & 3)) x[K >> 2] = xk;
+#pragma unroll
+    for (int i = K >> 2; i < 4; ++i) {
+      // column 4i+g is updated only if it lies right of K (lanes of slot K>>2 with g <= K&3 are done)
+      if (i > (K >> 2) || g > (K & 3)) x[i] = __builtin_fma(-xk, lt[K][i], x[i]);
+    }
+    QuadSolve<K + 1>::run(x, lt, inv, g);
+  }
+};
+template <>
+struct QuadSolve<16> {
+  static __device__ __forceinline__ void run(double (&)[4], const double (&)[16][4], const double (&)[4], int) {}
+};
+
 // One elimination step of the 16x16 diagonal sub-block held one row per lane (a[c], c = 0..15):
 // square-root-free form, a_rc -= (a_rj / p_j) * a_cj for c > j, column j+1 first so that the next
 // pivot's reciprocal chain starts as early as possible.
@@ -157,8 +185,9 @@ __global__ __launch_bounds__(256, 1) void potrf_leaf128_kernel(double* __restric
                                                                 int* __restrict__ info) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* S = smem;                     // packed lower block-trapezoid, see soff()
-  double* LdT = smem + LEAF_ELEMS;      // [16][16]  LdT[k][c] = L16[c][k] (current diagonal sub-block)
-  double* invd = LdT + SB * SB;         // [128] 1 / L[c][c]
+  double* LdT2 = smem + LEAF_ELEMS;     // [2][16][16]  LdT[k][c] = L16[c][k] of diagonal sub-block jb (buffer jb & 1)
+  double* invd = LdT2 + 2 * SB * SB;    // [128] 1 / L[c][c]
+  volatile int* sync_w = reinterpret_cast<volatile int*>(invd + LEAF);  // [0] rows published by wave 0, [1] arrivals of waves 1..3
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -167,122 +196,185 @@ __global__ __launch_bounds__(256, 1) void potrf_leaf128_kernel(double* __restric
   if (threadIdx.x == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory");
 #endif
 
-  // load the lower block-trapezoid, 16 B per lane per load, 8 loads in flight
-  {
-    typedef double double2_t __attribute__((ext_vector_type(2)));
-    double2_t v[8];
+  // load the lower block-trapezoid: wave 0 takes the first 16x16 block and starts factoring it while
+  // waves 1..3 stream in the other 4480 16-byte pieces (24 loads in flight per lane, one round trip)
+  typedef double double2_t __attribute__((ext_vector_type(2)));
+  if (wave == 0) {
+    double2_t v[2];
 #pragma unroll
-    for (int h = 0; h < 4; ++h) {
+    for (int u = 0; u < 2; ++u) {
+      const int e = lane + 64 * u;  // 128 pieces of block row 0
+      v[u] = *reinterpret_cast<const double2_t*>(Ablk + (long)(e >> 3) * lda + 2 * (e & 7));
+    }
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int e = tid + 256 * (q + 8 * h);  // 16-byte piece index: row = e >> 6, col pair = e & 63
-        const int r = e >> 6, c2 = 2 * (e & 63);
-        if (c2 < 16 * ((r >> 4) + 1)) v[q] = *reinterpret_cast<const double2_t*>(Ablk + (long)r * lda + c2);
+    for (int u = 0; u < 2; ++u) {
+      const int e = lane + 64 * u;
+      *reinterpret_cast<double2_t*>(S + soff(e >> 3) + 2 * (e & 7)) = v[u];
+    }
+    wave_lds_fence();
+  } else {
+    // row block b holds 16 rows x 8(b+1) pieces; compile-time b makes the div/mod cheap
+    const int t = tid - 64;
+    double2_t v[27];
+    int u = 0;
+#pragma unroll
+    for (int bb = 0; bb < 8; ++bb) {
+      const int per = 8 * (bb + 1), cnt = 16 * per, skip = (bb == 0) ? 128 : 0;  // block 0 belongs to wave 0
+#pragma unroll
+      for (int idx0 = skip; idx0 < cnt; idx0 += 192) {
+        const int idx = idx0 + t;
+        if (idx < cnt) v[u] = *reinterpret_cast<const double2_t*>(Ablk + (long)(16 * bb + idx / per) * lda + 2 * (idx % per));
+        ++u;
       }
+    }
+    u = 0;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int e = tid + 256 * (q + 8 * h);
-        const int r = e >> 6, c2 = 2 * (e & 63);
-        if (c2 < 16 * ((r >> 4) + 1)) *reinterpret_cast<double2_t*>(S + soff(r) + c2) = v[q];
+    for (int bb = 0; bb < 8; ++bb) {
+      const int per = 8 * (bb + 1), cnt = 16 * per, skip = (bb == 0) ? 128 : 0;
+#pragma unroll
+      for (int idx0 = skip; idx0 < cnt; idx0 += 192) {
+        const int idx = idx0 + t;
+        if (idx < cnt) *reinterpret_cast<double2_t*>(S + soff(16 * bb + idx / per) + 2 * (idx % per)) = v[u];
+        ++u;
       }
     }
   }
-  __syncthreads();
-  LEAF_STAMP(0);
+  // (A): factor the 16x16 diagonal sub-block jb in registers (wave 0; lanes 16..63 mirror lanes 0..15)
+  auto factor_diag = [&](int jb) {
+    const int j0 = jb * SB;
+    const int r = lane & 15;
+    double a[SB];
+    {
+      const double* row = S + soff(j0 + r) + j0;
+#pragma unroll
+      for (int c = 0; c < SB; ++c) a[c] = row[c];
+    }
+    int bad = 0;
+    ElimStep<0>::run(a, mov_rowbcast<0>(a[0]), bad);
+    if (bad != 0 && lane == 0) atomicMin(info, col0 + j0 + bad);
+    // normalise: L[r][c] = a[c] * rsqrt(p_c); lane c holds p_c = a[c]
+    const double rs = fast_rsqrt(a[r]);
+    double l[SB];
+    ScaleCols<0>::run(a, rs, l);
+    double* row = S + soff(j0 + r) + j0;
+    double* LdT = LdT2 + (jb & 1) * SB * SB;
+#pragma unroll
+    for (int c = 0; c < SB; ++c) {
+      if (lane < SB && c <= r) {
+        row[c] = l[c];
+        LdT[c * SB + r] = l[c];
+      }
+    }
+    if (lane < SB) invd[j0 + r] = rs;
+  };
+  // (B) for one row: X = B * L16^-T by column-oriented forward substitution in registers
+  auto solve_row = [&](int jb, int rowidx) {
+    const int j0 = jb * SB;
+    const double* LdT = LdT2 + (jb & 1) * SB * SB;
+    double* row = S + soff(rowidx) + j0;
+    double x[SB];
+#pragma unroll
+    for (int c = 0; c < SB; ++c) x[c] = row[c];
+#pragma unroll
+    for (int k = 0; k < SB; ++k) {
+      x[k] *= invd[j0 + k];
+#pragma unroll
+      for (int c = k + 1; c < SB; ++c) x[c] = __builtin_fma(-x[k], LdT[k * SB + c], x[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < SB; ++c) row[c] = x[c];
+  };
+  // (C) one 16x16 tile of the trailing update: S[r0.., c0..] -= X[r0..] X[c0..]^T with X = columns j0..j0+15
+  auto update_tile = [&](int j0, int r0, int c0) {
+    const int n = lane & 15, kq = lane >> 4;
+    double4_t acc;
+    double av[4], bv[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      av[s4] = S[soff(r0 + n) + j0 + 4 * s4 + kq];  // X[r0 + (l&15)][k = 4s + (l>>4)]
+      bv[s4] = S[soff(c0 + n) + j0 + 4 * s4 + kq];  // X[c0 + (l&15)][k]
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = S[soff(r0 + kq + 4 * r) + c0 + n];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[s4], bv[s4], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) S[soff(r0 + kq + 4 * r) + c0 + n] = acc[r];
+  };
 
+  LEAF_STAMP(0);
+  if (tid == 64) { sync_w[0] = 0; sync_w[1] = 0; }
+  if (wave == 0) factor_diag(0);
+  __syncthreads();
+  LEAF_STAMP(1);
+  // Per 16-column block jb, after the diagonal sub-block jb has been factored:
+  //   wave 0     : solves the 16 rows of the NEXT diagonal block, publishes them, updates the next diagonal
+  //                tile and factors it (the serial chain of the leaf);
+  //   waves 1..3 : solve the remaining rows, meet each other and wave 0's rows through two LDS words, apply
+  //                the rank-16 MFMA update to every other trailing tile and stream column block jb out.
   for (int jb = 0; jb < LEAF / SB; ++jb) {
     const int j0 = jb * SB;
-    // ---- (A) 16x16 diagonal sub-block in registers (wave 0; lanes 16..63 mirror lanes 0..15)
     if (wave == 0) {
-      const int r = lane & 15;
-      double a[SB];
-      {
-        const double* row = S + soff(j0 + r) + j0;
+      if (jb + 1 < LEAF / SB) {
+        {  // the 16 rows of the next diagonal block, four lanes per row
+          const int g = lane & 3;
+          double* row = S + soff(j0 + SB + (lane >> 2)) + j0;
+          double x[4];
 #pragma unroll
-        for (int c = 0; c < SB; ++c) a[c] = row[c];
+          for (int i = 0; i < 4; ++i) x[i] = row[4 * i + g];
+          const double* LdT = LdT2 + (jb & 1) * SB * SB;
+          double lt[16][4], inv[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) inv[i] = invd[j0 + 4 * i + g];
+#pragma unroll
+          for (int k = 0; k < 15; ++k)
+#pragma unroll
+            for (int i = k >> 2; i < 4; ++i) lt[k][i] = LdT[k * SB + 4 * i + g];
+          __builtin_amdgcn_sched_barrier(0);
+          QuadSolve<0>::run(x, lt, inv, g);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) row[4 * i + g] = x[i];
+        }
+        wave_lds_fence();
+        if (lane == 0) sync_w[0] = jb + 1;
+        LEAF_STAMP(2);
+        update_tile(j0, j0 + SB, j0 + SB);
+        wave_lds_fence();
+        LEAF_STAMP(6);
+        factor_diag(jb + 1);
+        LEAF_STAMP(7);
       }
-      int bad = 0;
-      ElimStep<0>::run(a, mov_rowbcast<0>(a[0]), bad);
-      if (bad != 0 && lane == 0) atomicMin(info, col0 + j0 + bad);
-      // normalise: L[r][c] = a[c] * rsqrt(p_c); lane c holds p_c = a[c]
-      const double rs = fast_rsqrt(a[r]);
-      double l[SB];
-      ScaleCols<0>::run(a, rs, l);
-      double* row = S + soff(j0 + r) + j0;
-#pragma unroll
-      for (int c = 0; c < SB; ++c) {
-        if (lane < SB && c <= r) {
-          row[c] = l[c];
-          LdT[c * SB + r] = l[c];
+    } else {
+      const int t = tid - 64;
+      const int nrest = LEAF - j0 - 2 * SB;  // rows j0+32 .. 127
+      if (t < nrest) solve_row(jb, j0 + 2 * SB + t);
+      if (jb + 1 < LEAF / SB) {
+        wave_lds_fence();
+        if (lane == 0) atomicAdd(const_cast<int*>(sync_w + 1), 1);
+        while (sync_w[1] < 3 * (jb + 1) || sync_w[0] < jb + 1) __builtin_amdgcn_s_sleep(1);
+        wave_lds_fence();
+      }
+      // column block jb is final for rows >= j0: 8 pieces of 16 B per row
+      for (int it = t; it < (LEAF - j0) * 8; it += 192) {
+        const int r = j0 + (it >> 3), c2 = j0 + 2 * (it & 7);
+        if (c2 <= r) {
+          const double2_t v = *reinterpret_cast<const double2_t*>(S + soff(r) + c2);
+          double* dst = Ablk + (long)r * lda + c2;
+          if (c2 + 1 <= r) *reinterpret_cast<double2_t*>(dst) = v;
+          else dst[0] = v.x;
         }
       }
-      if (lane < SB) invd[j0 + r] = rs;
-    }
-    __syncthreads();
-    LEAF_STAMP(1);
-    // ---- (B) rows below: X = B * L16^-T, one thread per row, column-oriented forward substitution
-    {
-      const int nrow = LEAF - j0 - SB;  // rows j0+16 .. 127
-      if (tid < nrow) {
-        double* row = S + soff(j0 + SB + tid) + j0;
-        double x[SB];
-#pragma unroll
-        for (int c = 0; c < SB; ++c) x[c] = row[c];
-#pragma unroll
-        for (int k = 0; k < SB; ++k) {
-          x[k] *= invd[j0 + k];
-#pragma unroll
-          for (int c = k + 1; c < SB; ++c) x[c] = __builtin_fma(-x[k], LdT[k * SB + c], x[c]);
-        }
-#pragma unroll
-        for (int c = 0; c < SB; ++c) row[c] = x[c];
-      }
-    }
-    __syncthreads();
-    LEAF_STAMP(2);
-    // ---- (C) trailing update S[i-tile][c-tile] -= X_i X_c^T on fp64 MFMA (rank 16), lower tiles only
-    {
       const int q = LEAF / SB - 1 - jb;  // trailing tiles per dimension
-      const int n = lane & 15, kq = lane >> 4;
       int e = 0;
-      for (int tr = 0; tr < q; ++tr) {
-        for (int tc = 0; tc <= tr; ++tc, ++e) {
-          if ((e & 3) != wave) continue;
-          const int r0 = j0 + SB + 16 * tr, c0 = j0 + SB + 16 * tc;
-          double4_t acc;
-          double av[4], bv[4];
-#pragma unroll
-          for (int s4 = 0; s4 < 4; ++s4) {
-            av[s4] = S[soff(r0 + n) + j0 + 4 * s4 + kq];  // X[r0 + (l&15)][k = 4s + (l>>4)]
-            bv[s4] = S[soff(c0 + n) + j0 + 4 * s4 + kq];  // X[c0 + (l&15)][k]
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[r] = S[soff(r0 + kq + 4 * r) + c0 + n];
-#pragma unroll
-          for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[s4], bv[s4], acc, 0, 0, 0);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) S[soff(r0 + kq + 4 * r) + c0 + n] = acc[r];
+      for (int tr = 1; tr < q; ++tr) {  // tile row 0 = tile (0,0) belongs to wave 0
+        for (int tc = 0; tc <= tr; ++tc) {
+          if ((e++ % 3) != wave - 1) continue;
+          update_tile(j0, j0 + SB + 16 * tr, j0 + SB + 16 * tc);
         }
       }
     }
     __syncthreads();
     LEAF_STAMP(3);
-  }
-
-  // ---- write L back (whole rows up to and including the diagonal's pair; upper part is don't-care)
-  {
-    typedef double double2_t __attribute__((ext_vector_type(2)));
-#pragma unroll 8
-    for (int it = 0; it < 32; ++it) {
-      const int e = tid + 256 * it;
-      const int r = e >> 6, c2 = 2 * (e & 63);
-      if (c2 <= r) {
-        const double2_t v = *reinterpret_cast<const double2_t*>(S + soff(r) + c2);
-        double* dst = Ablk + (long)r * lda + c2;
-        if (c2 + 1 <= r) *reinterpret_cast<double2_t*>(dst) = v;
-        else dst[0] = v.x;
-      }
-    }
   }
   LEAF_STAMP(4);
   // ---- inverses of the eight 16x16 diagonal sub-blocks: thread (b, c) solves column c of block b
@@ -414,7 +506,7 @@ __global__ __launch_bounds__(256) void trsm_strip128_kernel(const double* __rest
     for (int r = 0; r < 4; ++r) Brow[16 * j + 4 * r + q] = T[j][r];
 }
 
-constexpr size_t LEAF_LDS_BYTES = sizeof(double) * (LEAF_ELEMS + SB * SB + LEAF);
+constexpr size_t LEAF_LDS_BYTES = sizeof(double) * (LEAF_ELEMS + 2 * SB * SB + LEAF + 2);
 constexpr size_t STRIP_LDS_BYTES = sizeof(double) * STRIP_TILES * 256;
 
 hipError_t leaf_enable_lds() {

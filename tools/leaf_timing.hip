@@ -26,7 +26,7 @@ int main() {
     float ms; hipEventElapsedTime(&ms, e0, e1); best = std::min(best, ms);
   }
   unsigned long long st[8]; hipMemcpyFromSymbol(st, HIP_SYMBOL(g_leaf_stamps), sizeof(st));
-  printf("leaf kernel %.1f us; cycles: load %llu | A(diag) %llu | B(trsm) %llu | C(update) %llu | store %llu | dinv %llu\n", best * 1e3, st[0], st[1], st[2], st[3], st[4], st[5]);
+  printf("leaf kernel %.1f us; cycles: load %llu | A(diag) %llu | B(trsm) %llu | C(update) %llu | store %llu | dinv %llu || w0: tile %llu factor %llu\n", best * 1e3, st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7]);
   hipMemcpy(A.data(), dA, A.size() * 8, hipMemcpyDeviceToHost);
   // check L L^T = A0
   double err = 0;

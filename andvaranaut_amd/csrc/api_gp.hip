@@ -22,6 +22,7 @@ struct mi_gp_handle {
   hipEvent_t ev_panel, ev_upd;
   int lookahead;
   int use_graph;
+  int lowocc_thr;  // trailing sizes (tile columns) at or below which bulk updates run one workgroup per CU
   int w_thr[3];  // trailing sizes (tile columns) above which the super-panel is 16 / 8 / 4 tiles wide
   std::map<int, hipGraphExec_t> graphs;  // captured evaluation DAGs, keyed by (what, options)
   mi_gp_buffers buf;
@@ -101,6 +102,7 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_upd, hipEventDisableTiming);
   h->lookahead = 1;
   h->use_graph = 1;
+  h->lowocc_thr = 64;
   h->w_thr[0] = 1 << 20; h->w_thr[1] = 72; h->w_thr[2] = 0;
   if (e == hipSuccess) e = hipMalloc(&h->theta_dev, sizeof(double) * h->ntheta);
   if (e == hipSuccess) e = hipMalloc(&h->out_dev, sizeof(double) * 16);
@@ -170,6 +172,7 @@ extern "C" int mi_gp_set_option(mi_gp_handle* h, int what, int value) {
   else if (what == 3) h->use_graph = value ? 1 : 0;
   else if (what >= 4 && what <= 6) h->w_thr[what - 4] = value;
   else if (what == 7) set_gemm_small_tiles(value);
+  else if (what == 8) h->lowocc_thr = value;
   else return -1;
   return 0;
 }
@@ -208,8 +211,9 @@ static hipError_t prof_gemm(mi_gp_handle* h, const GemmParams& p, int ak, int bk
 
 // trapezoid update  A[r0:, c0:c0+nc] -= P P_c^T  with P = A[r0:, k0:k0+kw] (tile units)
 static hipError_t syrk_trapezoid(mi_gp_handle* h, double* A, long lda, int ntr, int r0, int nc, int k0, int kw,
-                                 hipStream_t st) {
+                                 hipStream_t st, int one_per_cu = 0) {
   GemmParams p;
+  p.one_per_cu = one_per_cu;
   p.A = A + (long)r0 * 128 * lda + (long)k0 * 128;
   p.B = p.A;
   p.C = A + (long)r0 * 128 * lda + (long)r0 * 128;
@@ -257,7 +261,7 @@ static hipError_t chol_panel(mi_gp_handle* h, double* A, long lda, int ntr, int 
 // TFLOP/s instead of ~57 at k = 512), narrower ones once the panel chain is the critical path
 static int pick_w(const mi_gp_handle* h, int rem) {
   int W = h->cfg.panel_tiles;
-  if (W <= 0) W = (rem > h->w_thr[0]) ? 16 : (rem > h->w_thr[1]) ? 8 : (rem > h->w_thr[2]) ? 4 : 4;
+  if (W <= 0) W = (rem > h->w_thr[0]) ? 16 : (rem > h->w_thr[1]) ? 8 : (rem > h->w_thr[2]) ? 4 : 2;
   return rem < W ? rem : W;
 }
 
@@ -287,7 +291,7 @@ static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int nt
     }
     CKE(chol_panel(h, A, lda, ntr, n1, wn, P));
     // (b) the rest of the trailing matrix, concurrently with that panel factorisation
-    if (n1 + wn < ntc) CKE(syrk_trapezoid(h, A, lda, ntr, n1 + wn, ntc - n1 - wn, J, w, T));
+    if (n1 + wn < ntc) CKE(syrk_trapezoid(h, A, lda, ntr, n1 + wn, ntc - n1 - wn, J, w, T, (P != T && ntc - n1 <= h->lowocc_thr) ? 1 : 0));
     J = n1;
     w = wn;
   }
@@ -338,7 +342,7 @@ static int run_evaluation(mi_gp_handle* h, int what) {
     return download_results(h, what);
   }
   const int key = what | (h->lookahead << 4) | ((h->cfg.panel_tiles & 0xff) << 8) | (gemm_variant_get() << 20) |
-                  ((h->w_thr[0] * 31 + h->w_thr[1] * 7 + h->w_thr[2]) & 0x7ff) << 21;
+                  ((h->w_thr[0] * 31 + h->w_thr[1] * 7 + h->w_thr[2] + h->lowocc_thr * 13) & 0x7ff) << 21;
   auto it = h->graphs.find(key);
   if (it == h->graphs.end()) {
     // First use: time one evaluation with plain launches, then capture + instantiate and time a

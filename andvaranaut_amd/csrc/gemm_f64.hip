@@ -20,6 +20,7 @@
 // K7 triangular inverse levels (NN with triangular k-ranges) and L^-T L^-1 (TN), K8 predict
 // triangular-solve updates (NT).
 #include <cstdlib>
+#include <type_traits>
 #include "migp_kernels.h"
 
 namespace migp {
@@ -331,12 +332,21 @@ __global__ __launch_bounds__(vb::NT_B, 2) void gemm_f64_kernel_b(GemmParams p) {
   const long stepB = (B_KMAJOR ? (long)BKB * p.ldb : (long)BKB) * 8;
   char* Asb = reinterpret_cast<char*>(As);
   char* Bsb = reinterpret_cast<char*>(Bs);
-  double2_t ra[NQB], rb[NQB];
+  // Global -> register prefetch runs TWO chunks ahead (register set c & 1 holds chunk c until it is written to
+  // LDS buffer c & 1 during chunk c - 1): ~7k cycles of latency tolerance instead of ~3k, enough for an
+  // HBM / MALL miss under load while two workgroups share the CU.
+  double2_t ra[2][NQB], rb[2][NQB];
   if (nchunk > 0) {
-    vb::chunk_load(Ag, gA, sA, ra);
-    vb::chunk_load(Bg, gB, sB, rb);
-    vb::chunk_store<A_KMAJOR>(Asb, lA, ra);
-    vb::chunk_store<B_KMAJOR>(Bsb, lB, rb);
+    vb::chunk_load(Ag, gA, sA, ra[0]);
+    vb::chunk_load(Bg, gB, sB, rb[0]);
+    if (nchunk > 1) {
+      Ag += stepA;
+      Bg += stepB;
+      vb::chunk_load(Ag, gA, sA, ra[1]);
+      vb::chunk_load(Bg, gB, sB, rb[1]);
+    }
+    vb::chunk_store<A_KMAJOR>(Asb, lA, ra[0]);
+    vb::chunk_store<B_KMAJOR>(Bsb, lB, rb[0]);
   }
   __syncthreads();
 
@@ -354,15 +364,17 @@ __global__ __launch_bounds__(vb::NT_B, 2) void gemm_f64_kernel_b(GemmParams p) {
   };
   if (nchunk > 0) load_frags(0, 0, 0);
 
-  for (int c = 0; c < nchunk; ++c) {
-    const int boff = (c & 1) * OPER_B;
-    const bool more = (c + 1 < nchunk);
-    if (more) {
+  // one chunk; S = c & 1 selects both the LDS buffer being consumed and the register set being refilled
+  auto chunk_body = [&](int c, auto S) {
+    constexpr int s = decltype(S)::value;
+    constexpr int boff = s * OPER_B;
+    if (c + 2 < nchunk) {
       Ag += stepA;
       Bg += stepB;
-      vb::chunk_load(Ag, gA, sA, ra);
-      vb::chunk_load(Bg, gB, sB, rb);
+      vb::chunk_load(Ag, gA, sA, ra[s]);
+      vb::chunk_load(Bg, gB, sB, rb[s]);
     }
+    const bool more = (c + 1 < nchunk);
 #pragma unroll
     for (int kk = 0; kk < BKB / 4; ++kk) {
       const int cur = kk & 1;
@@ -375,13 +387,17 @@ __global__ __launch_bounds__(vb::NT_B, 2) void gemm_f64_kernel_b(GemmParams p) {
           acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur][a], bf[cur][b], acc[a][b], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       if (kk == BKB / 4 - 2 && more) {
-        const int noff = (boff ^ OPER_B) * 8;
-        vb::chunk_store<A_KMAJOR>(Asb + noff, lA, ra);
-        vb::chunk_store<B_KMAJOR>(Bsb + noff, lB, rb);
+        constexpr int noff = (boff ^ OPER_B) * 8;
+        vb::chunk_store<A_KMAJOR>(Asb + noff, lA, ra[s ^ 1]);
+        vb::chunk_store<B_KMAJOR>(Bsb + noff, lB, rb[s ^ 1]);
       }
     }
     __syncthreads();
     if (more) load_frags(0, boff ^ OPER_B, 0);
+  };
+  for (int c = 0; c < nchunk; c += 2) {  // k is a multiple of 128, so nchunk is even
+    chunk_body(c, std::integral_constant<int, 0>());
+    chunk_body(c + 1, std::integral_constant<int, 1>());
   }
 
   const double alpha = p.alpha, beta = p.beta;
@@ -580,6 +596,7 @@ static int gemm_variant() {
 }
 
 static int g_small_tiles = 1024;
+constexpr size_t LDS_ONE_PER_CU = 84 * 1024;  // 160 KB per CU: two of these do not fit, one + a 76 KB leaf does
 void set_gemm_variant(int v) { g_variant = v; }
 void set_gemm_small_tiles(int v) { g_small_tiles = v; }
 static int tile_count(const GemmParams& p);
@@ -605,7 +622,7 @@ hipError_t launch_gemm_f64(const GemmParams& p, int opA_kmajor, int opB_kmajor, 
   }
   if (gemm_variant() == 1) {
     dim3 grid(nblk, 1, batch), block(vb::NT_B);
-    const size_t lds = sizeof(double) * 4 * vb::OPER_B;
+    const size_t lds = p.one_per_cu ? LDS_ONE_PER_CU : sizeof(double) * 4 * vb::OPER_B;
     if (!opA_kmajor && !opB_kmajor) gemm_f64_kernel_b<false, false><<<grid, block, lds, stream>>>(p);
     else if (!opA_kmajor && opB_kmajor) gemm_f64_kernel_b<false, true><<<grid, block, lds, stream>>>(p);
     else if (opA_kmajor && opB_kmajor) gemm_f64_kernel_b<true, true><<<grid, block, lds, stream>>>(p);
@@ -634,7 +651,7 @@ hipError_t gemm_f64_enable_lds() {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
   }
-  const int ldsb = (int)(sizeof(double) * 4 * vb::OPER_B);
+  const int ldsb = (int)LDS_ONE_PER_CU;
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_kernel_b<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_kernel_b<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);

@@ -17,6 +17,8 @@ struct GemmParams {
   int tri;                         // 1: only tiles with tj <= min(ti, nt-1)  (SYRK / trapezoid)
   int kmode;                       // 0 full k; 1 k >= tj*128; 2 k < (ti+1)*128; 3 k >= ti*128; 4 k < (tj+1)*128
   double alpha, beta;
+  int one_per_cu = 0;               // launcher only: request > half a CU's LDS so that one workgroup per CU runs (leaves room for
+                                    // the panel chain's leaf / strip kernels next to a bulk update)
 };
 // opX_kmajor = 0: operand stored [x][k] (A row-major m x k / B stored n x k, i.e. "B^T");
 // opX_kmajor = 1: operand stored [k][x].

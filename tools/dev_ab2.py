@@ -10,7 +10,7 @@ X, y = orc.synth_problem(N, d, seed=0)
 theta = orc.synth_theta(d)
 gp = MiGP(X, y, "Matern52", need_grad=False)
 ref = gp.lml(theta)
-configs = [(1 << 20, 72, 0), (112, 72, 0), (104, 64, 0), (96, 56, 0), (1 << 20, 56, 0), (1 << 20, 88, 0), (80, 48, 0)]
+configs = [(1 << 20, 72, 0), (1 << 20, 72, 16), (1 << 20, 72, 32), (1 << 20, 96, 0), (1 << 20, 48, 0), (1 << 20, 56, 24), (1 << 20, 40, 0), (1 << 20, 64, 0)]
 res = {c: [] for c in configs}
 for rnd in range(3):
     for c in configs:

@@ -64,6 +64,9 @@ def load():
     lib.mi_gp_lml.argtypes = [vp, dp, dp]
     lib.mi_gp_lml_parts.argtypes = [vp, dp, dp]
     lib.mi_gp_lml_grad.argtypes = [vp, dp, dp, dp]
+    lib.mi_gp_alpha.argtypes = [vp, dp]
+    lib.mi_gp_grad_x.argtypes = [vp, vp]
+    lib.mi_gp_set_diag.argtypes = [vp, vp]
     lib.mi_gp_factor.argtypes = [vp, dp]
     lib.mi_gp_predict.argtypes = [vp, vp, ci, vp, cl, vp, vp, ci]
     lib.mi_gp_set_option.argtypes = [vp, ci, ci]
@@ -93,6 +96,9 @@ EXPORTS = [
     "mi_gp_lml",
     "mi_gp_lml_parts",
     "mi_gp_lml_grad",
+    "mi_gp_alpha",
+    "mi_gp_grad_x",
+    "mi_gp_set_diag",
     "mi_gp_factor",
     "mi_gp_predict",
     "mi_gp_set_option",

@@ -115,6 +115,54 @@ class MiGP:
         self.info = self._check(self.lib.mi_gp_lml_grad(self.h, tp, ctypes.byref(out), gp_), "mi_gp_lml_grad")
         return out.value, grad
 
+    def lml_grad_data(self, theta, want_x=True):
+        """(LML, dLML/dtheta, dLML/dy, dLML/dX) -- the data-side gradients drive the chain rule through
+        warps (cwgp / iwgp) and free input rows (inverse_opt).  dLML/dX is None unless want_x."""
+        val, grad = self.lml_grad(theta)
+        if not np.isfinite(val):
+            return val, grad, np.zeros(self.n), (np.zeros((self.n, self.d)) if want_x else None)
+        alpha = np.empty(self.n)
+        self._check(self.lib.mi_gp_alpha(self.h, alpha.ctypes.data_as(ctypes.POINTER(ctypes.c_double))), "mi_gp_alpha")
+        gx = None
+        if want_x:
+            with torch.cuda.device(self.dev):
+                if getattr(self, "_gx_t", None) is None:
+                    self._gx_t = torch.empty((self.n, self.d), dtype=torch.float64, device=self.dev)
+                    torch.cuda.synchronize(self.dev)
+                self._check(self.lib.mi_gp_grad_x(self.h, self._gx_t.data_ptr()), "mi_gp_grad_x")
+                gx = self._gx_t.cpu().numpy()
+        return val, grad, -alpha, gx
+
+    def update_data(self, X=None, y=None):
+        """Overwrite the resident inputs / outputs in place (same shapes): warped data change at every
+        posterior evaluation while the buffers, the handle and its captured graphs stay."""
+        with torch.cuda.device(self.dev):
+            if X is not None:
+                X = np.ascontiguousarray(X, dtype=np.float64)
+                if X.shape != (self.n, self.d):
+                    raise ValueError("X must keep its shape")
+                self.X_t.copy_(torch.from_numpy(X))
+            if y is not None:
+                y = np.ascontiguousarray(np.asarray(y, dtype=np.float64).reshape(-1))
+                if y.shape != (self.n,):
+                    raise ValueError("y must keep its shape")
+                self.y_t.copy_(torch.from_numpy(y))
+            torch.cuda.synchronize(self.dev)
+
+    def set_diag(self, diag=None):
+        """Per-point diagonal added to K at assembly (None removes it)."""
+        with torch.cuda.device(self.dev):
+            if diag is None:
+                self._diag_t = None
+                self._check(self.lib.mi_gp_set_diag(self.h, None), "mi_gp_set_diag")
+                return
+            diag = np.ascontiguousarray(np.asarray(diag, dtype=np.float64).reshape(-1))
+            if diag.shape != (self.n,):
+                raise ValueError("diag must have n entries")
+            self._diag_t = torch.from_numpy(diag).to(self.dev)
+            torch.cuda.synchronize(self.dev)
+            self._check(self.lib.mi_gp_set_diag(self.h, self._diag_t.data_ptr()), "mi_gp_set_diag")
+
     def factor(self, theta):
         """Factorise for prediction (conditional form); returns LAPACK-style info."""
         theta, tp = self._theta(theta)

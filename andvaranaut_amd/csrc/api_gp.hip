@@ -51,6 +51,8 @@ struct mi_gp_handle {
   double t_trtri_ms, t_lauum_ms, t_contract_ms;
   double t_gemm_big_ms, gemm_big_flops, n_gemm_big;  // the 128x128-tile kernel only
   bool factored;
+  bool have_kinv;          // W_dev holds K^-1 (lower) and alpha_dev = K^-1 y of the last mi_gp_lml_grad
+  const double* diag_dev;  // optional per-point diagonal added at assembly (mi_gp_set_diag)
   char err[256];
 };
 
@@ -87,6 +89,8 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   h->device = cfg->device;
   h->have_data = false;
   h->factored = false;
+  h->have_kinv = false;
+  h->diag_dev = nullptr;
   h->t_trtri_ms = h->t_lauum_ms = h->t_contract_ms = 0.0;
   h->t_gemm_big_ms = h->gemm_big_flops = h->n_gemm_big = 0.0;
   h->prof_level = 0;
@@ -305,7 +309,7 @@ static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int nt
 static int enqueue_factor(mi_gp_handle* h, int noise_form, bool prof) {
   if (prof) hipEventRecord(h->ev[0], h->stream);
   HCK(launch_assemble(h->spec, h->theta_dev, h->buf.X_dev, h->n, h->buf.X_dev, h->n, h->buf.K_dev, h->buf.lda, h->np,
-                      h->np, 1, noise_form, h->stream), "assemble");
+                      h->np, 1, noise_form, h->stream, 0, h->diag_dev), "assemble");
   HCK(launch_set_yrows(h->buf.K_dev, h->buf.lda, h->np, h->np, h->buf.y_dev, h->n, h->stream), "set_yrows");
   if (prof) hipEventRecord(h->ev[1], h->stream);
   HCK(cholesky(h, h->buf.K_dev, h->buf.lda, h->ntc + 1, h->ntc), "cholesky");
@@ -393,6 +397,7 @@ static int run_evaluation(mi_gp_handle* h, int what) {
 
 static int factor_internal(mi_gp_handle* h, const double* theta, int what) {
   h->factored = false;
+  h->have_kinv = false;
   if (!h->have_data) { snprintf(h->err, sizeof(h->err), "mi_gp_set_data has not been called"); return -1; }
   HCK(hipSetDevice(h->device), "hipSetDevice");
   for (int i = 0; i < h->ntheta; ++i) {
@@ -540,6 +545,43 @@ extern "C" int mi_gp_lml_grad(mi_gp_handle* h, const double* theta, double* lml_
   if (r > 0) { *lml_out = -INFINITY; return r; }
   *lml_out = h->out_host[0];
   for (int i = 0; i < h->ntheta; ++i) grad_out[i] = h->grad_host[i];
+  h->have_kinv = true;
+  return 0;
+}
+
+// Data-side gradients of the LML at the theta of the last successful mi_gp_lml_grad (whose K^-1 and alpha are
+// still resident): dLML/dy = -alpha and dLML/dX.  They feed the chain rule through the reference's output and
+// input warps (cwgp / iwgp, gpmcmc.py:211-279) and through the free observation rows of inverse_opt
+// (gpmcmc.py:1096-1101), which PyMC differentiates by autodiff through the same Cholesky.
+extern "C" int mi_gp_alpha(mi_gp_handle* h, double* alpha_host) {
+  if (!h || !alpha_host) return -1;
+  if (!h->have_kinv) { snprintf(h->err, sizeof(h->err), "mi_gp_alpha: call mi_gp_lml_grad first"); return -1; }
+  HCK(hipSetDevice(h->device), "hipSetDevice");
+  HCK(hipMemcpyAsync(alpha_host, h->alpha_dev, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->stream), "alpha download");
+  HCK(hipStreamSynchronize(h->stream), "stream sync");
+  return 0;
+}
+
+extern "C" int mi_gp_grad_x(mi_gp_handle* h, double* gx_dev) {
+  if (!h || !gx_dev) return -1;
+  if (!h->have_kinv) { snprintf(h->err, sizeof(h->err), "mi_gp_grad_x: call mi_gp_lml_grad first"); return -1; }
+  if (h->cfg.d > 128) { snprintf(h->err, sizeof(h->err), "mi_gp_grad_x: d <= 128"); return -1; }
+  HCK(hipSetDevice(h->device), "hipSetDevice");
+  HCK(launch_grad_x(h->spec, h->theta_dev, h->buf.X_dev, h->n, h->buf.W_dev, h->buf.lda, h->alpha_dev, gx_dev, h->stream),
+      "grad_x");
+  HCK(hipStreamSynchronize(h->stream), "stream sync");
+  return 0;
+}
+
+// Optional per-point diagonal (n doubles on the device, borrowed; nullptr removes it) added to K at assembly on
+// top of the (gv, jitter) terms of theta: the observation-noise vector of inverse_opt (gpmcmc.py:1134-1158).
+extern "C" int mi_gp_set_diag(mi_gp_handle* h, const double* diag_dev) {
+  if (!h) return -1;
+  h->diag_dev = diag_dev;
+  h->factored = false;
+  h->have_kinv = false;
+  for (auto& kv : h->graphs) if (kv.second) hipGraphExecDestroy(kv.second);  // the pointer is baked into the captured DAG
+  h->graphs.clear();
   return 0;
 }
 

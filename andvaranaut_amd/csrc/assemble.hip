@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void assemble_kernel(KernSpec spec, const doub
                                                        const double* __restrict__ X2, int n2,
                                                        double* __restrict__ K, long ldk, int rows_pad,
                                                        int cols_pad, int sym, int noise_form,
-                                                       int diag_shift) {
+                                                       int diag_shift, const double* __restrict__ extra_diag) {
   __shared__ double Xi[AT * DLD];
   __shared__ double Xj[AT * DLD];
   __shared__ double n2i[AT], n2j[AT];
@@ -133,6 +133,7 @@ __global__ __launch_bounds__(256) void assemble_kernel(KernSpec spec, const doub
         if (noise_form == 0) { v += sg * sg; v += jitter; }       // Marginal._build_marginal_likelihood
         else if (noise_form == 1) { v += jitter; v += sg * sg; }  // Marginal._build_conditional
         else { v += jitter + gv; }                                // gpmcmc.py:312 explicit form
+        if (extra_diag) v += extra_diag[gi];                      // per-point noise vector (inverse_opt, gpmcmc.py:1134-1158)
       }
       K[(long)gi * ldk + gj] = v;
     }
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(1024) void lml_reduce_kernel(const double* __restri
 
 hipError_t launch_assemble(const KernSpec& spec, const double* theta, const double* X1, int n1, const double* X2,
                            int n2, double* K, long ldk, int rows_pad, int cols_pad, int sym, int noise_form,
-                           hipStream_t stream, int diag_shift) {
+                           hipStream_t stream, int diag_shift, const double* extra_diag) {
   int nblk;
   if (sym) {
     const int nt = rows_pad / AT;
@@ -190,7 +191,7 @@ hipError_t launch_assemble(const KernSpec& spec, const double* theta, const doub
     nblk = (rows_pad / AT) * (cols_pad / AT);
   }
   assemble_kernel<<<nblk, 256, 0, stream>>>(spec, theta, X1, n1, X2, n2, K, ldk, rows_pad, cols_pad, sym, noise_form,
-                                            sym ? 0 : diag_shift);
+                                            sym ? 0 : diag_shift, sym ? extra_diag : nullptr);
   return hipGetLastError();
 }
 

@@ -272,6 +272,190 @@ __global__ __launch_bounds__(256) void grad_contract_kernel(KernSpec spec, const
   }
 }
 
+// dLML/dX (n x d, row-major) for the inputs-as-parameters consumers (input warping, gpmcmc.py:211-233; the
+// free observation rows of inverse_opt, gpmcmc.py:1096-1101):
+//   dLML/dx_im = sum_j (alpha_i alpha_j - Kinv_ij) dK_ij/dx_im
+//              = sum_c sum_j Wsym_ij coef_c kv_c k_c'(r2_c) * 2 (x_im - x_jm) / l_cm^2
+// (row i and column i of the symmetric sum 1/2 tr(W dK) contribute equally).  One workgroup per block of
+// 64 rows walks all 64-column blocks: pass 1 builds the coefficient tile C_c (same 4x4 micro-tiles as
+// grad_contract) and parks it in LDS, pass 2 is the small dense product C_c (64x64) . (x_i - X_j) with
+// thread (row, m mod 4).  Kinv is stored as its lower triangle only; the upper part is read transposed.
+constexpr int GXCH = 16;  // input dimensions per LDS chunk
+constexpr int GXLD = GXCH + 1;
+constexpr int GX_MAXD = 128;
+
+template <int NK, int NCH>  // NCH: chunks of 16 input dimensions covered (d <= 16 * NCH)
+__global__ __launch_bounds__(256) void grad_x_kernel(KernSpec spec, const double* __restrict__ theta,
+                                                     const double* __restrict__ X, int n,
+                                                     const double* __restrict__ W, long ldw,
+                                                     const double* __restrict__ alpha_v, double* __restrict__ gx) {
+  __shared__ double Xi[GT * GXLD];
+  __shared__ double Xj[GT * GXLD];
+  __shared__ double Ct[GT * (GT + 1)];
+  __shared__ double ils[NK * GX_MAXD];  // 1 / l_cm
+  const int tid = threadIdx.x;
+  const int d = spec.d;
+  const int nt = (n + GT - 1) / GT;
+  const int ib = blockIdx.x, i0 = ib * GT;
+  const int tx = tid & 15, ty = tid >> 4;  // pass-1 micro-tile: rows ty+16a, cols tx+16b
+  const int pr = tid & 63, pq = tid >> 6;  // pass-2: row pr, dimensions m = pq (mod 4)
+  const double* kv = theta + NK * d;
+  const double* al = kv + NK;
+  for (int e = tid; e < NK * d; e += 256) ils[(e / d) * GX_MAXD + e % d] = 1.0 / theta[e];
+  double acc[NCH][GXCH / 4];
+#pragma unroll
+  for (int mc = 0; mc < NCH; ++mc)
+#pragma unroll
+    for (int u = 0; u < GXCH / 4; ++u) acc[mc][u] = 0.0;
+
+  for (int jb = 0; jb < nt; ++jb) {
+    const int j0 = jb * GT;
+    __syncthreads();  // previous block's pass 2 is done with Ct / Xj
+    // symmetric weight tile, coalesced along whichever index is contiguous in the stored lower triangle
+    for (int e = tid; e < GT * GT; e += 256) {
+      int r, c;
+      if (jb <= ib) { r = e >> 6; c = e & 63; } else { c = e >> 6; r = e & 63; }
+      const int gi = i0 + r, gj = j0 + c;
+      double w = 0.0;
+      if (gi < n && gj < n) {
+        const double kin = (gj <= gi) ? W[(long)gi * ldw + gj] : W[(long)gj * ldw + gi];
+        w = alpha_v[gi] * alpha_v[gj] - kin;
+      }
+      Ct[r * (GT + 1) + c] = w;
+    }
+    // pass 1: scaled squared distances per component
+    double r2[NK][4][4];
+#pragma unroll
+    for (int c = 0; c < NK; ++c)
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) r2[c][a][b] = 0.0;
+    for (int m0 = 0; m0 < d; m0 += GXCH) {
+      const int dc = min(GXCH, d - m0);
+      if (m0 > 0) __syncthreads();
+      for (int e = tid; e < GT * GXCH; e += 256) {
+        const int r = e / GXCH, m = e % GXCH;
+        double vi = 0.0, vj = 0.0;
+        if (m < dc) {
+          if (i0 + r < n) vi = X[(long)(i0 + r) * d + m0 + m];
+          if (j0 + r < n) vj = X[(long)(j0 + r) * d + m0 + m];
+        }
+        Xi[r * GXLD + m] = vi;
+        Xj[r * GXLD + m] = vj;
+      }
+      __syncthreads();
+      for (int m = 0; m < dc; ++m) {
+        double xi[4], xj[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) xi[a] = Xi[(ty + 16 * a) * GXLD + m];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) xj[b] = Xj[(tx + 16 * b) * GXLD + m];
+#pragma unroll
+        for (int c = 0; c < NK; ++c) {
+          const double il = ils[c * GX_MAXD + m0 + m];
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+              const double df = (xi[a] - xj[b]) * il;
+              r2[c][a][b] += df * df;
+            }
+        }
+      }
+    }
+    // coefficient tiles cf[c] = Wsym * (dK/dK_c of the fold) * kv_c dk_c/dr2
+    double cf[NK][4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        double kval[NK], dkv[NK];
+#pragma unroll
+        for (int c = 0; c < NK; ++c) {
+          double k, dk, da;
+          base_kernel_val_der(spec.kid[c], r2[c][a][b], al[c], k, dk, da);
+          kval[c] = kv[c] * k;
+          dkv[c] = kv[c] * dk;
+        }
+        double pref[NK];
+        double T = kval[0];
+        pref[0] = 1.0;
+#pragma unroll
+        for (int c = 1; c < NK; ++c) {
+          pref[c] = (spec.op[c - 1] == 0) ? 1.0 : T;
+          T = (spec.op[c - 1] == 0) ? T + kval[c] : T * kval[c];
+        }
+        const double w = Ct[(ty + 16 * a) * (GT + 1) + tx + 16 * b];
+#pragma unroll
+        for (int c = 0; c < NK; ++c) {
+          double coef = pref[c];
+#pragma unroll
+          for (int c2 = c + 1; c2 < NK; ++c2)
+            if (spec.op[c2 - 1] == 1) coef *= kval[c2];
+          cf[c][a][b] = w * coef * dkv[c];
+        }
+      }
+    // pass 2, one component at a time through the LDS tile
+#pragma unroll
+    for (int c = 0; c < NK; ++c) {
+      __syncthreads();  // everyone has read the weights (c == 0) / finished the previous component
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) Ct[(ty + 16 * a) * (GT + 1) + tx + 16 * b] = cf[c][a][b];
+#pragma unroll
+      for (int mc = 0; mc < NCH; ++mc) {
+        const int m0 = mc * GXCH;
+        if (m0 >= d) break;
+        const int dc = min(GXCH, d - m0);
+        if (NCH > 1) {  // several chunks: bring this one back (a single chunk is still resident)
+          __syncthreads();
+          for (int e = tid; e < GT * GXCH; e += 256) {
+            const int r = e / GXCH, m = e % GXCH;
+            double vi = 0.0, vj = 0.0;
+            if (m < dc) {
+              if (i0 + r < n) vi = X[(long)(i0 + r) * d + m0 + m];
+              if (j0 + r < n) vj = X[(long)(j0 + r) * d + m0 + m];
+            }
+            Xi[r * GXLD + m] = vi;
+            Xj[r * GXLD + m] = vj;
+          }
+        }
+        __syncthreads();
+        double t[GXCH / 4], xr[GXCH / 4];
+#pragma unroll
+        for (int u = 0; u < GXCH / 4; ++u) {
+          t[u] = 0.0;
+          xr[u] = Xi[pr * GXLD + pq + 4 * u];
+        }
+        for (int j = 0; j < GT; ++j) {
+          const double cj = Ct[pr * (GT + 1) + j];
+#pragma unroll
+          for (int u = 0; u < GXCH / 4; ++u) t[u] += cj * (xr[u] - Xj[j * GXLD + pq + 4 * u]);
+        }
+#pragma unroll
+        for (int u = 0; u < GXCH / 4; ++u) {
+          const int m = m0 + pq + 4 * u;
+          if (pq + 4 * u < dc) {
+            const double il = ils[c * GX_MAXD + m];
+            acc[mc][u] += 2.0 * il * il * t[u];
+          }
+        }
+      }
+    }
+  }
+  if (i0 + pr < n) {
+#pragma unroll
+    for (int mc = 0; mc < NCH; ++mc)
+#pragma unroll
+      for (int u = 0; u < GXCH / 4; ++u) {
+        const int m = mc * GXCH + pq + 4 * u;
+        if (m < d) gx[(long)(i0 + pr) * d + m] = acc[mc][u];
+      }
+  }
+}
+
 // grad[p] = sum_b part[b][p] in a fixed order (the weights already are 1 below the diagonal and 1/2
 // on it, which is 1/2 sum over the full symmetric matrix).
 __global__ void grad_final_kernel(const double* __restrict__ part, int nblk, int P, double* __restrict__ grad) {
@@ -341,6 +525,26 @@ hipError_t launch_grad_contract(const KernSpec& spec, const double* theta, const
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   grad_final_kernel<<<P, 256, 0, stream>>>(part, nblk, P, grad);
+  return hipGetLastError();
+}
+
+hipError_t launch_grad_x(const KernSpec& spec, const double* theta, const double* X, int n, const double* W, long ldw,
+                         const double* alpha, double* gx, hipStream_t stream) {
+  if (spec.d > GX_MAXD) return hipErrorInvalidValue;
+  const int nblk = (n + GT - 1) / GT;
+#define GX_LAUNCH(NK_)                                                                                    \
+  do {                                                                                                   \
+    if (spec.d <= GXCH) grad_x_kernel<NK_, 1><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, gx);          \
+    else if (spec.d <= 2 * GXCH) grad_x_kernel<NK_, 2><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, gx); \
+    else grad_x_kernel<NK_, GX_MAXD / GXCH><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, gx);            \
+  } while (0)
+  switch (spec.nkern) {
+    case 1: GX_LAUNCH(1); break;
+    case 2: GX_LAUNCH(2); break;
+    case 3: GX_LAUNCH(3); break;
+    default: GX_LAUNCH(4); break;
+  }
+#undef GX_LAUNCH
   return hipGetLastError();
 }
 

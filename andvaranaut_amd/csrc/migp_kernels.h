@@ -54,7 +54,7 @@ struct KernSpec {
 // sym=0: full K(X1,X2), zeros in the padding.  noise_form: 0 marginal, 1 conditional, 2 explicit.
 hipError_t launch_assemble(const KernSpec& spec, const double* theta, const double* X1, int n1, const double* X2,
                            int n2, double* K, long ldk, int rows_pad, int cols_pad, int sym, int noise_form,
-                           hipStream_t stream, int diag_shift = -2147483647 - 1);
+                           hipStream_t stream, int diag_shift = -2147483647 - 1, const double* extra_diag = nullptr);
 // diag_shift (sym=0 only): local element (i, j) is on the global diagonal when i + diag_shift == j
 // (rectangular blocks of a distributed covariance); the default means "no diagonal" (cross-covariance).
 hipError_t launch_set_yrows(double* K, long ldk, int row0, int cols_pad, const double* y, int n, hipStream_t stream);
@@ -67,6 +67,9 @@ int grad_contract_blocks(int n);
 // part: [grad_contract_blocks(n)][ntheta] scratch; grad: [ntheta] (natural parameters, C-ABI order)
 hipError_t launch_grad_contract(const KernSpec& spec, const double* theta, const double* X, int n, const double* W,
                                 long ldw, const double* alpha, double* part, double* grad, hipStream_t stream);
+// gx: [n][d] dLML/dX from Kinv (lower triangle in W) and alpha; d <= 128
+hipError_t launch_grad_x(const KernSpec& spec, const double* theta, const double* X, int n, const double* W, long ldw,
+                         const double* alpha, double* gx, hipStream_t stream);
 hipError_t launch_predict_reduce(const double* A, long lda, const double* beta, int n, int m, double kdiag,
                                  double noise, double* mean, double* var, hipStream_t stream);
 

@@ -75,6 +75,18 @@ int mi_gp_lml_parts(mi_gp_handle* h, double* logdet_out, double* quad_out);
  * pm.find_MAP (gpmcmc.py:332,345,357) and pm.sample / NUTS (gpmcmc.py:351) call per step. */
 int mi_gp_lml_grad(mi_gp_handle* h, const double* theta_host, double* lml_out, double* grad_out);
 
+/* Data-side gradients at the theta of the last successful mi_gp_lml_grad (K^-1 and alpha still resident):
+ *   mi_gp_alpha  : alpha = K^-1 y (n doubles to the host); dLML/dy = -alpha
+ *   mi_gp_grad_x : dLML/dX (n x d row-major, device), dLML/dx_im = sum_j (alpha_i alpha_j - Kinv_ij) dK_ij/dx_im
+ * They carry the chain rule through the output / input warps whose parameters the reference samples together
+ * with the hyper-parameters (cwgp / iwgp, gpmcmc.py:211-279, Jacobian term :319) and through the free
+ * observation rows of inverse_opt (gpmcmc.py:1096-1101,1156-1165); PyMC obtains both by autodiff.  d <= 128. */
+int mi_gp_alpha(mi_gp_handle* h, double* alpha_host);
+int mi_gp_grad_x(mi_gp_handle* h, double* gx_dev);
+/* Optional per-point diagonal (n doubles, device, borrowed; NULL removes it) added to K on top of theta's
+ * (gv, jitter): the noise vector `ynoise` of inverse_opt (gpmcmc.py:1134-1158, K += diag(ynoise)). */
+int mi_gp_set_diag(mi_gp_handle* h, const double* diag_dev);
+
 /* Factorise K(theta) + jitter I + gv I (the conditional's form, [3P] Marginal._build_conditional) and
  * keep L and beta = L^-1 y on the device for mi_gp_predict.  Replaces the first half of
  * gp.predict(x, point=hyps, diag=True, pred_noise=True) at gpmcmc.py:593-594. */

@@ -144,7 +144,7 @@ def kernel_diag(kerns, ops, theta, d):
 
 
 # ----------------------------------------------------------------------- K2..K6
-def noisy_cov(X, kerns, ops, theta, form="marginal"):
+def noisy_cov(X, kerns, ops, theta, form="marginal", extra_diag=None):
     """K2.  form='marginal': [3P] Marginal._build_marginal_likelihood:
     (Kxx + WhiteNoise(sigma)) + jitter*I with sigma=sqrt(gv) (gpmcmc.py:321-323), so the
     diagonal gets sqrt(gv)**2.  form='explicit': K + I*(jitter+gv) (gpmcmc.py:312).
@@ -166,14 +166,16 @@ def noisy_cov(X, kerns, ops, theta, form="marginal"):
         K[idx, idx] += s * s
     else:
         raise ValueError(form)
+    if extra_diag is not None:  # inverse_opt's K += diag(ynoise) (gpmcmc.py:1158)
+        K[idx, idx] += np.asarray(extra_diag, dtype=np.float64)
     return K
 
 
-def lml(X, y, kerns, ops, theta, form="marginal", return_parts=False):
+def lml(X, y, kerns, ops, theta, form="marginal", return_parts=False, extra_diag=None):
     """K3,K4,K6.  [3P] MvNormal.logp via quaddist_chol (scipy.linalg.cholesky lower +
     solve_triangular), == gpmcmc.py:313-318 without the warp Jacobian.
     Non-PD -> -inf ([3P] check_parameters 'posdef')."""
-    K = noisy_cov(X, kerns, ops, theta, form)
+    K = noisy_cov(X, kerns, ops, theta, form, extra_diag)
     n = len(y)
     try:
         L = sla.cholesky(K, lower=True)
@@ -232,6 +234,44 @@ def lml_grad(X, y, kerns, ops, theta, form="marginal"):
     g[nk * d + 2 * nk] = 0.5 * np.trace(W)
     g[nk * d + 2 * nk + 1] = 0.5 * np.trace(W)
     return val, g
+
+
+def lml_grad_data(X, y, kerns, ops, theta, form="marginal", extra_diag=None):
+    """Data-side gradients of the LML: (LML, dLML/dy, dLML/dX).
+        dLML/dy = -alpha,   dLML/dx_im = sum_j (alpha_i alpha_j - Kinv_ij) dK_ij/dx_im
+    (row i and column i of 1/2 tr(W dK) contribute equally).  The reference gets them by autodiff when
+    warp parameters (cwgp / iwgp, gpmcmc.py:211-279) or observation inputs (inverse_opt,
+    gpmcmc.py:1096-1101) are random variables of the PyMC model."""
+    d = X.shape[1]
+    nk = len(kerns)
+    ls, kv, alpha, gv, jitter = split_theta(theta, d, nk)
+    val, L, beta = lml(X, y, kerns, ops, theta, form, return_parts=True, extra_diag=extra_diag)
+    n = len(y)
+    if L is None:
+        return val, np.zeros(n), np.zeros((n, d))
+    a = sla.solve_triangular(L, beta, lower=True, trans="T")
+    Kinv = sla.cho_solve((L, True), np.eye(n))
+    W = np.outer(a, a) - Kinv
+    comps, r2s = component_matrices(X, None, kerns, ls, kv, alpha)
+    pref = [None] * nk
+    T = comps[0]
+    pref[0] = np.ones_like(T)
+    for i in range(1, nk):
+        pref[i] = np.ones_like(T) if ops[i - 1] == "+" else T.copy()
+        T = T + comps[i] if ops[i - 1] == "+" else T * comps[i]
+    gX = np.zeros((n, d))
+    for c in range(nk):
+        coef = pref[c]
+        for i in range(c + 1, nk):
+            if ops[i - 1] == "*":
+                coef = coef * comps[i]
+        dk = kv[c] * base_kernel_dr2(kerns[c], r2s[c], alpha[c])
+        dk = np.where(r2s[c] > 0.0, dk, 0.0)
+        G = W * coef * dk
+        for m in range(d):
+            diff = X[:, m : m + 1] - X[:, m : m + 1].T
+            gX[:, m] += np.sum(G * diff, axis=1) * (2.0 / ls[c, m] ** 2)
+    return val, -a, gX
 
 
 # --------------------------------------------------------------------------- K8

@@ -1,0 +1,126 @@
+"""Parity of the data-side gradients (dLML/dy = -alpha, dLML/dX) and of the per-point noise diagonal with
+the oracle: the quantities the reference's autodiff supplies when warp parameters (cwgp / iwgp,
+gpmcmc.py:211-279) or observation inputs (inverse_opt, gpmcmc.py:1096-1165) are model variables."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _mods():
+    import torch
+
+    assert torch.cuda.is_available()
+    from andvaranaut_amd import MiGP
+    from oracle import gp_oracle as orc
+
+    return MiGP, orc
+
+
+def _split(kernel):
+    return kernel.replace("*", "+").split("+"), [c for c in kernel if c in "+*"]
+
+
+CASES = [(1, 1, "RBF"), (3, 2, "Matern52"), (64, 2, "RBF"), (65, 3, "Matern32"), (200, 16, "Matern52"),
+         (513, 17, "RBF"), (700, 33, "Matern52"), (640, 5, "RBF*Matern52"), (900, 2, "RBF+Matern52*Exponential"),
+         (300, 3, "RatQuad"), (1500, 8, "Matern32+RBF")]
+
+
+@pytest.mark.parametrize("N,d,kernel", CASES)
+def test_data_gradients_match_oracle(N, d, kernel):
+    MiGP, orc = _mods()
+    X, y = orc.synth_problem(max(N, 3), d, seed=3 * N + d)
+    X, y = X[:N], y[:N]
+    kerns, ops = _split(kernel)
+    theta = orc.synth_theta(d, nkern=len(kerns), gv=1e-3)
+    gp = MiGP(X, y, kernel)
+    val, g, gy, gX = gp.lml_grad_data(theta)
+    ref, gy_ref, gX_ref = orc.lml_grad_data(X, y, kerns, ops, theta)
+    assert abs(val - ref) <= 1e-9 * abs(ref)
+    tol = 1e-6 if "Exponential" in kernel else 1e-8
+    assert np.abs(gy - gy_ref).max() <= tol * max(np.abs(gy_ref).max(), 1e-300)
+    assert gX.shape == (N, d)
+    assert np.abs(gX - gX_ref).max() <= tol * max(np.abs(gX_ref).max(), 1e-300), np.abs(gX - gX_ref).max()
+    gp.close()
+
+
+def test_data_gradients_finite_differences_through_the_device():
+    """Independent of the oracle: central differences of the device LML in X and y."""
+    MiGP, orc = _mods()
+    X, y = orc.synth_problem(150, 3, seed=11)
+    theta = orc.synth_theta(3, gv=1e-3)
+    gp = MiGP(X, y, "Matern52")
+    _, _, gy, gX = gp.lml_grad_data(theta)
+    h = 1e-6
+    for i, m in ((0, 0), (17, 2), (149, 1)):
+        Xp, Xm = X.copy(), X.copy()
+        Xp[i, m] += h
+        Xm[i, m] -= h
+        gp.update_data(X=Xp)
+        fp = gp.lml(theta)
+        gp.update_data(X=Xm)
+        fm = gp.lml(theta)
+        assert abs((fp - fm) / (2 * h) - gX[i, m]) <= 2e-5 * max(1.0, abs(gX[i, m]))
+    gp.update_data(X=X)
+    for i in (3, 99):
+        yp, ym = y.copy(), y.copy()
+        yp[i] += h
+        ym[i] -= h
+        gp.update_data(y=yp)
+        fp = gp.lml(theta)
+        gp.update_data(y=ym)
+        fm = gp.lml(theta)
+        assert abs((fp - fm) / (2 * h) - gy[i]) <= 2e-5 * max(1.0, abs(gy[i]))
+    gp.close()
+
+
+def test_update_data_matches_fresh_handle():
+    MiGP, orc = _mods()
+    X, y = orc.synth_problem(400, 4, seed=2)
+    X2, y2 = orc.synth_problem(400, 4, seed=9)
+    theta = orc.synth_theta(4)
+    gp = MiGP(X, y, "RBF")
+    a = gp.lml(theta)
+    gp.update_data(X=X2, y=y2)
+    b = gp.lml(theta)
+    gp2 = MiGP(X2, y2, "RBF")
+    assert b == gp2.lml(theta) and a != b
+    gp.close()
+    gp2.close()
+
+
+@pytest.mark.parametrize("N,kernel", [(5, "RBF"), (300, "Matern52"), (1000, "RBF+Matern32")])
+def test_extra_diagonal(N, kernel):
+    """K + diag(v): LML, gradient and data gradients with a per-point noise vector (gpmcmc.py:1134-1158)."""
+    MiGP, orc = _mods()
+    d = 3
+    X, y = orc.synth_problem(N, d, seed=N)
+    kerns, ops = _split(kernel)
+    theta = orc.synth_theta(d, nkern=len(kerns), gv=0.0, jitter=0.0)
+    rng = np.random.default_rng(0)
+    v = 10.0 ** rng.uniform(-5, -2, N)
+    gp = MiGP(X, y, kernel)
+    gp.set_diag(v)
+    val, g, gy, gX = gp.lml_grad_data(theta)
+    ref, gy_ref, gX_ref = orc.lml_grad_data(X, y, kerns, ops, theta, extra_diag=v)
+    assert abs(val - ref) <= 1e-9 * abs(ref)
+    assert np.abs(gy - gy_ref).max() <= 1e-8 * np.abs(gy_ref).max()
+    assert np.abs(gX - gX_ref).max() <= 1e-8 * np.abs(gX_ref).max()
+    assert abs(gp.lml(theta) - ref) <= 1e-9 * abs(ref)
+    gp.set_diag(None)
+    theta2 = orc.synth_theta(d, nkern=len(kerns))
+    assert abs(gp.lml(theta2) - orc.lml(X, y, kerns, ops, theta2)) <= 1e-9 * abs(ref)
+    gp.close()
+
+
+def test_data_gradients_need_a_gradient_evaluation_first():
+    MiGP, orc = _mods()
+    X, y = orc.synth_problem(50, 2, seed=0)
+    gp = MiGP(X, y, "RBF")
+    gp.lml(orc.synth_theta(2))
+    import ctypes
+
+    out = np.empty(50)
+    r = gp.lib.mi_gp_alpha(gp.h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+    assert r == -1 and b"mi_gp_lml_grad" in gp.lib.mi_gp_last_error(gp.h)
+    gp.close()

@@ -4,8 +4,10 @@ an MI355X through libmi_gp.so instead of PyMC / PyTensor / SciPy-LAPACK.
 
 Same constructor, ``set_data`` / ``sample`` / ``fit`` / ``predict`` / ``change_model`` signatures and the
 same ``hypers`` dictionary keys as the reference (gpmcmc.py:31-32,122,158,175-177,472,522-523;
-keys recorded at tutorial/tutorial.ipynb:529).  Out of scope here: dask-parallel
-target execution, input/output warping inside the posterior (iwgp/cwgp), BO, inverse_opt, plots."""
+keys recorded at tutorial/tutorial.ipynb:529), including the warped fits ``fit(iwgp=True)`` /
+``fit(cwgp=True)`` whose warp parameters are optimised / sampled with the hyper-parameters
+(gpmcmc.py:211-279,319): the device supplies dLML/dX and dLML/dy, torch.autograd carries them through the
+warps.  Out of scope here: dask-parallel target execution, plots."""
 import copy
 import os
 import re
@@ -19,7 +21,7 @@ from .lhc import latin_sample
 from .nuts import Trace, sample_chain
 from .optimize import find_MAP
 from .priors import HyperModel
-from .transform import _none_conrev
+from .transform import _none_conrev, wgp
 
 
 class GPMCMC:
@@ -199,15 +201,116 @@ class GPMCMC:
         yin = self.yconrevs[0].con(y[:, 0])  # only y[:,0] is modelled (gpmcmc.py:279)
         return np.ascontiguousarray(xin), np.ascontiguousarray(yin)
 
+    # -- warps whose parameters are model variables (gpmcmc.py:211-279, 433-462)
+    def cwgp_set(self, params, mode="numpy", y=None):
+        """Set (mode='numpy') or build (otherwise) the output warp with new parameters (gpmcmc.py:433-441)."""
+        if y is None:
+            y = self.y - self.ym
+        warper = wgp(self.yconrevs[0].warping_names, params, y[:, 0], mode=mode)
+        if mode == "numpy":
+            self.change_yconrevs([warper])
+        else:
+            return warper
+
+    def iwgp_set(self, params, mode="numpy", x=None):
+        """Set / build the input warps with new parameters (gpmcmc.py:443-462)."""
+        if x is None:
+            x = self.x
+        xconrevs, rc = [], 0
+        for i in range(self.nx):
+            if isinstance(self.xconrevs[i], wgp):
+                ran = len(self.xconrevs[i].params)
+                xconrevs.append(wgp(self.xconrevs[i].warping_names, params[rc : rc + ran], y=x[:, i],
+                                    xdist=self.priors[i], mode=mode))
+                rc += ran
+            else:
+                xconrevs.append(self.xconrevs[i])
+        if mode == "numpy":
+            self.change_xconrevs(xconrevs=xconrevs)
+        else:
+            return xconrevs
+
+    def _warp_sizes(self, iwgp, cwgp):
+        n_i = n_pos = n_free = 0
+        if iwgp:
+            n_i = sum(c.np for c in self.xconrevs if isinstance(c, wgp))
+            if n_i == 0:
+                raise Exception("Error: iwgp set to true but none of xconrevs are wgp classes")
+        if cwgp:
+            if not isinstance(self.yconrevs[0], wgp):
+                raise Exception("Error: cwgp set to true but yconrevs class is not wgp")
+            if self.yconrevs[0].np == 0:
+                raise Exception("Error: cwgp set to true but wgp class has no tuneable parameters")
+            n_pos = int(np.sum(self.yconrevs[0].pos[: self.yconrevs[0].np]))
+            n_free = self.yconrevs[0].np - n_pos
+        return n_i, n_pos, n_free
+
+    def _cwgp_params(self, pos_vals, free_vals):
+        """Interleave the positive and unconstrained output-warp parameters in warp order (gpmcmc.py:263-275)."""
+        out, rc, rcpos = [], 0, 0
+        for i in range(self.yconrevs[0].np):
+            if self.yconrevs[0].pos[i]:
+                out.append(pos_vals[rcpos])
+                rcpos += 1
+            else:
+                out.append(free_vals[rc])
+                rc += 1
+        return out
+
+    def _warp_likelihood(self, gp, x, y, xin0, iwgp, cwgp):
+        """likelihood(values, theta) for HyperModel.logp_dlogp with warp variables: warp the data with the
+        current parameters (torch, host), evaluate LML + its theta / X / y gradients on the device, add the
+        warp Jacobian sum(log y') (gpmcmc.py:319) and pull the data gradients back onto the warp parameters."""
+        import torch
+
+        xt = torch.from_numpy(np.ascontiguousarray(x))
+        yt = torch.from_numpy(np.ascontiguousarray(y))
+
+        def likelihood(values, theta):
+            leaves = {}
+            xin_t = yin_t = yder_t = None
+            if iwgp:
+                leaves["iwgp"] = torch.tensor(values["iwgp"], dtype=torch.float64, requires_grad=True)
+                warpers = self.iwgp_set(leaves["iwgp"], mode="torch", x=xt)
+                cols = [warpers[i].conmc(xt[:, i]) if isinstance(warpers[i], wgp) else torch.from_numpy(xin0[:, i])
+                        for i in range(self.nx)]
+                xin_t = torch.stack(cols, dim=1)
+            if cwgp:
+                for nm in ("cwgp_pos", "cwgp"):
+                    if nm in values:
+                        leaves[nm] = torch.tensor(values[nm], dtype=torch.float64, requires_grad=True)
+                rvs = self._cwgp_params(leaves.get("cwgp_pos"), leaves.get("cwgp"))
+                warper = self.cwgp_set(torch.stack(list(rvs)), mode="torch", y=yt)
+                yin_t = warper.conmc(yt[:, 0])
+                yder_t = warper.dermc(yt[:, 0])
+                if not bool(torch.all(torch.isfinite(yin_t))) or not bool(torch.all(yder_t > 0)):
+                    return -np.inf, None, {}
+            gp.update_data(X=None if xin_t is None else xin_t.detach().numpy(),
+                           y=None if yin_t is None else yin_t.detach().numpy())
+            val, gth, gy, gx = gp.lml_grad_data(theta, want_x=iwgp)
+            if not np.isfinite(val):
+                return -np.inf, None, {}
+            s = torch.zeros((), dtype=torch.float64)
+            if cwgp:
+                s = s + (torch.from_numpy(gy) * yin_t).sum() + torch.log(yder_t).sum()
+                val = val + float(torch.log(yder_t).sum().detach())
+            if iwgp:
+                s = s + (torch.from_numpy(gx) * xin_t).sum()
+            s.backward()
+            return val, gth, {k: v.grad.numpy().copy() for k, v in leaves.items()}
+
+        return likelihood
+
     def __fit(self, x, y, method, iwgp, cwgp, jitter=1e-6, truncate=False, restarts=1, **kwargs):
-        if iwgp or cwgp:
-            raise NotImplementedError("input/output warping inside the posterior (gpmcmc.py:211-279) is not "
-                                      "part of this backend yet")
-        model = HyperModel(self.nx, self.kerns, noise=self.noise, truncate=truncate, jitter=jitter)
+        n_i, n_pos, n_free = self._warp_sizes(iwgp, cwgp)
+        model = HyperModel(self.nx, self.kerns, noise=self.noise, truncate=truncate, jitter=jitter, n_iwgp=n_i,
+                           n_cwgp_pos=n_pos, n_cwgp=n_free)
         xin, yin = self._converted(x, y)
         self.__release()
         gp = MiGP(xin, yin, self.kernel, device=self.device)
-        fun = lambda q: model.logp_dlogp(q, gp.lml_grad)  # noqa: E731
+        lik = self._warp_likelihood(gp, x, y, xin, iwgp, cwgp) if (iwgp or cwgp) else None
+        # pm.find_MAP maximises without the transform Jacobian, pm.sample with it (priors.py header)
+        fun_map = lambda q: model.logp_dlogp(q, gp.lml_grad, jacobian=False, likelihood=lik)  # noqa: E731
         data = None
         if method == "map":
             best, mp = -np.inf, None
@@ -215,7 +318,7 @@ class GPMCMC:
                 # the reference builds a random start and never passes it (gpmcmc.py:330-332): every
                 # restart begins at the model's initial point, so they coincide; kept as is
                 try:
-                    q, info = find_MAP(fun, model.initial_point(), progressbar=kwargs.get("progressbar", False),
+                    q, info = find_MAP(fun_map, model.initial_point(), progressbar=kwargs.get("progressbar", False),
                                        maxeval=kwargs.get("maxeval", 5000))
                 except Exception:
                     print("Restart failed")
@@ -229,22 +332,33 @@ class GPMCMC:
         elif method == "none":
             mp = self.hypers
         elif method in ("mcmc_mean", "mcmc_map"):
-            data = self.__sample(model, gp, xin, yin, **kwargs)
+            data = self.__sample(model, gp, x, y, xin, yin, iwgp, cwgp, **kwargs)
             if method == "mcmc_mean":
                 mp = self.mean_extract(data)
             else:
                 mp = self.map_extract(data)
                 try:
-                    q, _ = find_MAP(fun, model.q_from_point(mp))
+                    q, _ = find_MAP(fun_map, model.q_from_point(mp))
                     mp = model.point_dict(q)
                 except Exception:
                     pass
         else:
             raise Exception("method must be one of map, mcmc_map, or mcmc_mean")
+        # freeze the warps at the fitted parameters and leave the converted data on the device (gpmcmc.py:362-399)
+        if iwgp or cwgp:
+            if method != "none":
+                if iwgp:
+                    self.iwgp_set(np.atleast_1d(mp["iwgp"]))
+                if cwgp:
+                    self.cwgp_set(np.array(self._cwgp_params(np.atleast_1d(mp.get("cwgp_pos", [])),
+                                                              np.atleast_1d(mp.get("cwgp", [])))))
+            xin, yin = self._converted(x, y)
+            gp.update_data(X=xin, y=yin)
         return model, gp, mp, data
 
-    def __sample(self, model, gp, xin, yin, draws=1000, tune=1000, chains=None, cores=None, target_accept=0.8,
-                 random_seed=None, max_treedepth=10, progressbar=False, devices=None, **_):
+    def __sample(self, model, gp, x, y, xin, yin, iwgp=False, cwgp=False, draws=1000, tune=1000, chains=None,
+                 cores=None, target_accept=0.8, random_seed=None, max_treedepth=10, progressbar=False, devices=None,
+                 **_):
         """pm.sample(**kwargs) of gpmcmc.py:351: independent NUTS chains, one device handle per chain
         (one chain per GPU when several are visible: SURVEY.md section 8e)."""
         import torch
@@ -262,7 +376,8 @@ class GPMCMC:
         # chains that share a device run back to back on one handle; devices run concurrently
         def run_dev(dev, cs):
             h = handles.get(dev) or MiGP(xin, yin, self.kernel, device=dev)
-            f = lambda q: model.logp_dlogp(q, h.lml_grad)  # noqa: E731
+            lik = self._warp_likelihood(h, x, y, xin, iwgp, cwgp) if (iwgp or cwgp) else None
+            f = lambda q: model.logp_dlogp(q, h.lml_grad, likelihood=lik)  # noqa: E731
             for c in cs:
                 results[c] = sample_chain(f, model.initial_point(), draws=draws, tune=tune,
                                           target_accept=target_accept, max_treedepth=max_treedepth, seed=seeds[c],

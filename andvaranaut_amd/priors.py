@@ -9,10 +9,18 @@ reference builds with PyMC inside GPMCMC.__fit (gpmcmc.py:193-208):
     kv ~ LogNormal(0.56, 0.75)      shape nkern                (log)             [:208]
     kv ~ TruncatedNormal(1.0, 0.15, 1e-1, 100)                 (interval)        [:204-205]  truncate=True
     alpha ~ LogNormal(0.56, 0.75)   RatQuad only               (log)             [:288]
+    iwgp     ~ LogNormal(0, 0.25) | TruncatedNormal(1, 1, 1e-3, 5)    input-warp parameters   [:217-221]
+    cwgp_pos ~ LogNormal(0, 0.25) | TruncatedNormal(1, 1, 1e-3, 5)    positive output-warp parameters [:251-256]
+    cwgp     ~ Normal(0, 1)       | TruncatedNormal(0, 1, -10, 10)    the other output-warp parameters [:257-262]
 
 The logp / moment / transform formulas restate PyMC 5.9.2 (pymc/distributions/continuous.py,
 pymc/logprob/transforms.py), which is pinned only as ``pymc <= 5.9.2`` by the reference and is not
-installed here.  Variables are ordered as PyMC creates them in __fit: gv, l, kv, (alpha)."""
+installed here.  Variables are ordered as PyMC creates them in __fit: gv, l, kv, (iwgp), (cwgp_pos), (cwgp), (alpha).
+
+[3P] pm.find_MAP compiles the model's logp and dlogp with ``jacobian=False`` (pymc/tuning/starting.py): the
+optimiser moves the unconstrained vector but maximises the density of the constrained variables, without the
+log-determinant of the transform; pm.sample / NUTS uses the full transformed density.  ``logp_dlogp`` takes
+that switch as ``jacobian``."""
 import numpy as np
 from scipy.special import erf, expit
 
@@ -38,6 +46,23 @@ class LogNormal:
 
     def moment(self):
         return np.exp(self.mu + 0.5 * self.sigma ** 2)
+
+
+class Normal:
+    transform = None  # unconstrained: no transformed twin in the point dictionary
+
+    def __init__(self, mu, sigma):
+        self.mu, self.sigma = float(mu), float(sigma)
+
+    def logp(self, x):
+        z = (x - self.mu) / self.sigma
+        return -0.5 * z * z - LOG_SQRT_2PI - np.log(self.sigma)
+
+    def dlogp(self, x):
+        return -(x - self.mu) / self.sigma ** 2
+
+    def moment(self):
+        return self.mu
 
 
 class HalfNormal:
@@ -78,6 +103,8 @@ class TruncatedNormal:
 
 def forward(dist, x):
     """Constrained -> unconstrained value."""
+    if dist.transform is None:
+        return np.asarray(x, dtype=np.float64)
     if dist.transform == "log":
         return np.log(x)
     return np.log(x - dist.lower) - np.log(dist.upper - x)
@@ -85,6 +112,8 @@ def forward(dist, x):
 
 def backward(dist, q):
     """Unconstrained -> constrained value, d x / d q, log |dx/dq| and d log|dx/dq| / dq."""
+    if dist.transform is None:
+        return q, np.ones_like(q), np.zeros_like(q), np.zeros_like(q)
     if dist.transform == "log":
         x = np.exp(q)
         return x, x, q, np.ones_like(q)
@@ -98,7 +127,7 @@ class HyperModel:
     """Free hyper-parameters of one GP fit, in PyMC creation order, with the map between the flat
     unconstrained vector the optimiser / sampler moves and the C-ABI theta vector."""
 
-    def __init__(self, nx, kerns, noise=True, truncate=False, jitter=1e-6):
+    def __init__(self, nx, kerns, noise=True, truncate=False, jitter=1e-6, n_iwgp=0, n_cwgp_pos=0, n_cwgp=0):
         self.nx, self.kerns, self.nkern = int(nx), list(kerns), len(kerns)
         self.noise, self.truncate, self.jitter = bool(noise), bool(truncate), float(jitter)
         self.vars = []  # (name, dist, size)
@@ -111,13 +140,21 @@ class HyperModel:
         else:
             self.vars.append(("l", LogNormal(0.0, 1.0), nx * self.nkern, False))
             self.vars.append(("kv", LogNormal(0.56, 0.75), self.nkern, False))
+        warp_pos = (lambda: TruncatedNormal(1.0, 1.0, 1e-3, 5.0)) if truncate else (lambda: LogNormal(0.0, 0.25))
+        if n_iwgp > 0:
+            self.vars.append(("iwgp", warp_pos(), int(n_iwgp), False))
+        if n_cwgp_pos > 0:
+            self.vars.append(("cwgp_pos", warp_pos(), int(n_cwgp_pos), False))
+        if n_cwgp > 0:
+            self.vars.append(("cwgp", TruncatedNormal(0.0, 1.0, -10.0, 10.0) if truncate else Normal(0.0, 1.0),
+                              int(n_cwgp), False))
         if "RatQuad" in self.kerns:
             self.vars.append(("alpha", LogNormal(0.56, 0.75), 1, True))
         self.nq = sum(v[2] for v in self.vars)
         self.ntheta = self.nkern * self.nx + 2 * self.nkern + 2
 
     def transformed_name(self, name, dist):
-        return f"{name}_{dist.transform}__"
+        return name if dist.transform is None else f"{name}_{dist.transform}__"
 
     def initial_point(self):
         """[3P] model.initial_point(): transformed moments of the priors (find_MAP's default start)."""
@@ -154,20 +191,31 @@ class HyperModel:
         g["gv"] = np.array([gtheta[nk * nx + 2 * nk]])
         return g
 
-    def logp_dlogp(self, q, lml_grad):
+    def logp_dlogp(self, q, lml_grad, jacobian=True, likelihood=None):
         """Joint log-posterior in the unconstrained space and its gradient.
-        ``lml_grad(theta) -> (lml, dlml/dtheta)`` is the device callable (MiGP.lml_grad)."""
+        ``lml_grad(theta) -> (lml, dlml/dtheta)`` is the device callable (MiGP.lml_grad).  With warp
+        variables in the model, ``likelihood(values, theta) -> (loglik, dloglik/dtheta, {name: dloglik/dvalue})``
+        replaces it: it warps the data with the current parameters, evaluates the LML (+ warp Jacobian) on the
+        device and returns the extra gradients.  ``jacobian=False`` is what pm.find_MAP optimises."""
         parts = self.split(q)
         values, dxdq, prior, dprior = {}, {}, 0.0, {}
         for name, dist, _, _ in self.vars:
             x, dx, lj, dlj = backward(dist, parts[name])
             values[name], dxdq[name] = x, dx
-            prior += np.sum(dist.logp(x)) + np.sum(lj)
-            dprior[name] = dist.dlogp(x) * dx + dlj
-        lml, gtheta = lml_grad(self.theta(values))
+            prior += np.sum(dist.logp(x))
+            dprior[name] = dist.dlogp(x) * dx
+            if jacobian:
+                prior += np.sum(lj)
+                dprior[name] = dprior[name] + dlj
+        if likelihood is None:
+            lml, gtheta = lml_grad(self.theta(values))
+            gextra = {}
+        else:
+            lml, gtheta, gextra = likelihood(values, self.theta(values))
         if not np.isfinite(lml):
             return -np.inf, np.zeros(self.nq)
         gl = self._theta_grad_slices(gtheta)
+        gl.update(gextra)
         grad = np.concatenate([dprior[name] + gl[name] * dxdq[name] for name, _, _, _ in self.vars])
         return prior + lml, grad
 
@@ -179,7 +227,8 @@ class HyperModel:
         for name, dist, size, scalar in self.vars:
             x = backward(dist, parts[name])[0]
             tq = parts[name]
-            out[self.transformed_name(name, dist)] = np.array(tq[0]) if scalar else tq.copy()
+            if dist.transform is not None:
+                out[self.transformed_name(name, dist)] = np.array(tq[0]) if scalar else tq.copy()
             out[name] = np.array(x[0]) if scalar else x.copy()
         return out
 

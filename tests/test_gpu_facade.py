@@ -30,7 +30,7 @@ def test_config1_map_fit_matches_oracle_backed_map_and_predicts():
     # the same MAP problem driven by the oracle on the CPU lands on the same optimum
     xin, yin = g._converted(g.x, g.y - g.ym)
     model = HyperModel(2, ["RBF"], noise=False, jitter=1e-6)
-    f = lambda q: model.logp_dlogp(q, lambda th: orc.lml_grad(xin, yin, ["RBF"], [], th))  # noqa: E731
+    f = lambda q: model.logp_dlogp(q, lambda th: orc.lml_grad(xin, yin, ["RBF"], [], th), jacobian=False)  # noqa: E731
     q, info = find_MAP(f, model.initial_point())
     assert abs(info["logp"] - data["logp"]) <= 1e-6 * abs(info["logp"])
     assert np.allclose(g.hypers["l"], model.constrain(q)["l"], rtol=1e-4)
@@ -80,3 +80,74 @@ def test_mcmc_modes_short_chains():
     h = dict(g.hypers)
     g.fit(method="none")
     assert all(np.allclose(h[k], g.hypers[k]) for k in h)
+
+
+def _warped_problem(n=80, seed=4):
+    from andvaranaut_amd import GPMCMC
+    from andvaranaut_amd.transform import uniform, wgp
+
+    rng = np.random.default_rng(seed)
+    priors = [st.uniform(loc=0, scale=2), st.uniform(loc=1, scale=0.5)]
+    fun = lambda x: np.array([np.exp(1.5 * np.sin(2 * x[0] ** 1.5) + x[1] ** 2)])  # noqa: E731  positive, skewed output
+    x = np.column_stack([rng.uniform(0, 2, n), rng.uniform(1, 1.5, n)])
+    y = np.array([fun(r) for r in x])
+    xcon = [wgp(["uniform", "kumaraswamy"], np.array([1.0, 1.0]), y=x[:, 0], xdist=priors[0]), uniform(priors[1])]
+    ycon = [wgp(["logarithm", "meanstd", "sal"], np.array([0.0, 1.0, 0.0, 1.0]), y=y[:, 0])]
+    g = GPMCMC(kernel="Matern52", noise=True, xconrevs=xcon, yconrevs=ycon, nx=2, ny=1, priors=priors, target=fun,
+               verbose=False)
+    g.set_data(x, y)
+    return g, fun
+
+
+@pytest.mark.parametrize("iwgp,cwgp", [(False, True), (True, False), (True, True)])
+def test_warped_map_fit_device_gradient_and_oracle_agreement(iwgp, cwgp):
+    """fit(iwgp/cwgp) (gpmcmc.py:211-279,311-319,362-399): the device posterior and its gradient through the warps
+    equal the oracle-backed ones, the MAP lands on the same optimum, the warps are frozen at the fitted values."""
+    from andvaranaut_amd.optimize import find_MAP
+    from andvaranaut_amd.priors import HyperModel
+    from andvaranaut_amd.transform import wgp
+    from oracle import gp_oracle as orc
+    from test_host_logic import _OracleGP
+
+    g, fun = _warped_problem()
+    x, y = g.x.copy(), (g.y - g.ym).copy()
+    n_i, n_pos, n_free = g._warp_sizes(iwgp, cwgp)
+    model = HyperModel(2, ["Matern52"], noise=True, n_iwgp=n_i, n_cwgp_pos=n_pos, n_cwgp=n_free)
+    xin0, yin0 = g._converted(x, y)
+    # oracle-backed MAP of the same posterior (CPU), before the device fit changes the warps
+    lik_o = g._warp_likelihood(_OracleGP(xin0, yin0, ["Matern52"], []), x, y, xin0, iwgp, cwgp)
+    f_o = lambda q: model.logp_dlogp(q, None, jacobian=False, likelihood=lik_o)  # noqa: E731
+    q_o, info_o = find_MAP(f_o, model.initial_point())
+    data = g.fit(method="map", iwgp=iwgp, cwgp=cwgp, return_data=True)
+    assert abs(data["logp"] - info_o["logp"]) <= 1e-5 * abs(info_o["logp"]) + 1e-5
+    keys = set(g.hypers)
+    assert {"l", "kv", "gv"} <= keys and (("iwgp" in keys and "iwgp_log__" in keys) == iwgp)
+    assert (("cwgp" in keys and "cwgp_pos" in keys and "cwgp_pos_log__" in keys) == cwgp)
+    # the fitted warps are installed and the device holds the re-converted data (gpmcmc.py:362-399)
+    if iwgp:
+        assert isinstance(g.xconrevs[0], wgp) and np.allclose(g.xconrevs[0].params, g.hypers["iwgp"])
+    if cwgp:
+        assert np.allclose(np.asarray(g.yconrevs[0].params, dtype=float),
+                           g._cwgp_params(np.atleast_1d(g.hypers["cwgp_pos"]), np.atleast_1d(g.hypers["cwgp"])))
+    xin, yin = g._converted(x, y)
+    assert np.allclose(g.gp.X_t.cpu().numpy(), xin) and np.allclose(g.gp.y_t.cpu().numpy(), yin)
+    # device value and gradient at a generic point against the oracle-backed ones (this moves the device data)
+    lik_d = g._warp_likelihood(g.gp, x, y, xin0, iwgp, cwgp)
+    q = model.initial_point() + 0.1 * np.random.default_rng(0).standard_normal(model.nq)
+    vd, gd = model.logp_dlogp(q, None, likelihood=lik_d)
+    vo, go = model.logp_dlogp(q, None, likelihood=lik_o)
+    assert abs(vd - vo) <= 1e-9 * abs(vo) and np.abs(gd - go).max() <= 1e-7 * max(1.0, np.abs(go).max())
+    g.gp.update_data(X=xin, y=yin)
+    xt = np.random.default_rng(5).uniform([0, 1], [2, 1.5], (60, 2))
+    yt = np.array([fun(r) for r in xt])
+    yp = g.predict(xt)
+    rel = np.sqrt(np.mean(((yp - yt) / yt) ** 2))
+    assert rel < 0.05, rel
+
+
+def test_warped_mcmc_short_chain():
+    g, _ = _warped_problem(n=40)
+    data = g.fit(method="mcmc_mean", cwgp=True, return_data=True, draws=40, tune=40, chains=2, random_seed=3)
+    assert data.posterior["cwgp"].shape == (2, 40, 2) and data.posterior["cwgp_pos"].shape == (2, 40, 2)
+    assert np.all(np.isfinite(data.sample_stats["lp"]))
+    assert np.all(g.hypers["cwgp_pos"] > 0)

@@ -175,8 +175,117 @@ def test_facade_validates_arguments_and_fails_loudly_without_a_gpu():
     assert g.nsamp == 5
     with pytest.raises(Exception):
         g.set_data(x2 + 10.0, np.zeros((5, 1)))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(Exception, match="yconrevs class is not wgp"):  # gpmcmc.py:238-239
         g.fit(cwgp=True)
+    with pytest.raises(Exception, match="none of xconrevs are wgp"):  # gpmcmc.py:232-233
+        g.fit(iwgp=True)
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError):  # no CPU fallback for the hot path
             g.fit()
+
+
+# ----------------------------------------------------------------------------------------------- warps
+class _OracleGP:
+    """Stands in for andvaranaut_amd.MiGP on the CPU: same methods, arithmetic by the oracle (tests only)."""
+
+    def __init__(self, X, y, kerns, ops):
+        self.X, self.y, self.kerns, self.ops = X.copy(), y.copy(), kerns, ops
+
+    def update_data(self, X=None, y=None):
+        if X is not None:
+            self.X = np.array(X, dtype=np.float64)
+        if y is not None:
+            self.y = np.array(y, dtype=np.float64)
+
+    def lml_grad(self, theta):
+        return orc.lml_grad(self.X, self.y, self.kerns, self.ops, theta)
+
+    def lml_grad_data(self, theta, want_x=True):
+        val, g = self.lml_grad(theta)
+        _, gy, gX = orc.lml_grad_data(self.X, self.y, self.kerns, self.ops, theta)
+        return val, g, gy, gX
+
+
+def test_wgp_round_trip_derivative_and_parameter_bookkeeping():
+    from andvaranaut_amd.transform import wgp
+
+    rng = np.random.default_rng(0)
+    y = rng.lognormal(size=60) + 0.5
+    names = ["logarithm", "meanstd", "sal", "boxcox", "arcsinh", "stddev"]
+    params = np.array([0.1, 1.2, -0.2, 0.9, 0.05, 0.3, 1.1, -0.1, 0.8])
+    w = wgp(names, params, y=y)
+    assert w.np == 9 and list(w.pid) == [0, 0, 4, 5, 9, 9]
+    assert list(w.pos) == [False, True, False, True, False, False, True, False, True]
+    assert len(w.default_priors) == 9
+    yc = w.con(y)
+    assert np.allclose(w.rev(yc), y, rtol=1e-12)
+    h = 1e-6
+    assert np.allclose((w.con(y + h) - w.con(y - h)) / (2 * h), w.der(y), rtol=1e-7)
+    assert np.allclose(w.conmc(y), yc) and np.allclose(w.dermc(y), w.der(y))
+    # data-dependent members are fitted to the data as warped by the members before them (transform.py:543-548)
+    assert abs(np.std(yc) - 1.0) < 1e-12
+    with pytest.raises(Exception):
+        wgp(["meanstd"], np.zeros(0))  # needs y
+    with pytest.raises(Exception):
+        wgp(["foo"], np.zeros(0), y=y)
+    k = wgp(["uniform", "kumaraswamy"], np.array([1.3, 0.8]), y=rng.uniform(size=10), xdist=st.uniform(0, 1))
+    x = rng.uniform(0.05, 0.95, 20)
+    assert list(k.pos) == [True, True] and np.allclose(k.rev(k.con(x)), x, rtol=1e-12)
+
+
+@pytest.mark.parametrize("iwgp,cwgp,truncate", [(False, True, False), (True, False, False), (True, True, False),
+                                                (True, True, True)])
+def test_warped_posterior_gradient_by_finite_differences(iwgp, cwgp, truncate):
+    """logp of fit(iwgp=..., cwgp=...) (gpmcmc.py:211-279,311-319): gradient through the warps = device data
+    gradients (here the oracle's) pulled back by torch.autograd, against central differences."""
+    from andvaranaut_amd import GPMCMC
+    from andvaranaut_amd.priors import HyperModel
+    from andvaranaut_amd.transform import uniform, wgp
+
+    rng = np.random.default_rng(1)
+    priors = [st.uniform(loc=0, scale=2), st.uniform(loc=1, scale=0.5)]
+    fun = lambda x: np.array([np.exp(np.sin(2 * x[0]) + x[1] ** 2)])  # noqa: E731
+    x = np.column_stack([rng.uniform(0, 2, 30), rng.uniform(1, 1.5, 30)])
+    y = np.array([fun(r) for r in x])
+    xcon = [wgp(["uniform", "kumaraswamy"], np.array([1.0, 1.0]), y=x[:, 0], xdist=priors[0]), uniform(priors[1])]
+    ycon = [wgp(["logarithm", "meanstd", "sal"], np.array([0.0, 1.0, 0.0, 1.0]), y=y[:, 0])]
+    g = GPMCMC(kernel="Matern52", noise=True, xconrevs=xcon, yconrevs=ycon, nx=2, ny=1, priors=priors, target=fun,
+               verbose=False)
+    g.set_data(x, y)
+    n_i, n_pos, n_free = g._warp_sizes(iwgp, cwgp)
+    assert (n_i, n_pos, n_free) == (2 if iwgp else 0, 2 if cwgp else 0, 2 if cwgp else 0)
+    model = HyperModel(2, ["Matern52"], noise=True, truncate=truncate, n_iwgp=n_i, n_cwgp_pos=n_pos, n_cwgp=n_free)
+    xin, yin = g._converted(x, y)
+    fake = _OracleGP(xin, yin, ["Matern52"], [])
+    lik = g._warp_likelihood(fake, x, y, xin, iwgp, cwgp)
+    for jac in (True, False):
+        f = lambda q: model.logp_dlogp(q, None, jacobian=jac, likelihood=lik)  # noqa: E731
+        q = model.initial_point() + 0.1 * rng.standard_normal(model.nq)
+        v, grad = f(q)
+        assert np.isfinite(v)
+        for i in range(model.nq):
+            h = 1e-6
+            qp, qm = q.copy(), q.copy()
+            qp[i] += h
+            qm[i] -= h
+            fd = (f(qp)[0] - f(qm)[0]) / (2 * h)
+            assert abs(fd - grad[i]) <= 5e-5 * max(1.0, abs(fd)), (i, fd, grad[i])
+    names = [v[0] for v in model.vars]
+    assert names == ["gv", "l", "kv"] + (["iwgp"] if iwgp else []) + (["cwgp_pos", "cwgp"] if cwgp else [])
+    pt = model.point_dict(model.initial_point())
+    if cwgp:
+        assert "cwgp" in pt and ("cwgp_interval__" in pt if truncate else "cwgp_log__" not in pt)
+
+
+def test_find_map_objective_has_no_transform_jacobian():
+    """[3P] pm.find_MAP compiles logp with jacobian=False; NUTS keeps it: they differ by sum(log|dx/dq|)."""
+    from andvaranaut_amd.priors import HyperModel
+
+    X, y = orc.synth_problem(20, 2, seed=0)
+    model = HyperModel(2, ["RBF"], noise=True)
+    q = model.initial_point() + 0.05
+    cb = _oracle_callable(X, y, ["RBF"], [])
+    a, ga = model.logp_dlogp(q, cb, jacobian=True)
+    b, gb = model.logp_dlogp(q, cb, jacobian=False)
+    assert abs((a - b) - np.sum(q)) < 1e-9  # all three blocks are log-transformed: log|dx/dq| = q
+    assert np.allclose(ga - gb, 1.0)

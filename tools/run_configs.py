@@ -14,7 +14,7 @@ N, d = 16384, 16
 X, y = synth_problem(N, d, seed=0)
 gp = MiGP(X, y, "Matern52")
 model = HyperModel(d, ["Matern52"], noise=True, jitter=1e-6)
-f = lambda q: model.logp_dlogp(q, gp.lml_grad)
+f = lambda q: model.logp_dlogp(q, gp.lml_grad, jacobian=False)  # what pm.find_MAP optimises
 f(model.initial_point())
 t0 = time.perf_counter()
 q, info = find_MAP(f, model.initial_point(), maxeval=60)
@@ -30,7 +30,7 @@ X, y = synth_problem(N, d, seed=1)
 gp = MiGP(X, y, "RBF")
 model = HyperModel(d, ["RBF"], noise=True, jitter=1e-6)
 f = lambda q: model.logp_dlogp(q, gp.lml_grad)
-qmap, _ = find_MAP(f, model.initial_point(), maxeval=40)
+qmap, _ = find_MAP(lambda q: model.logp_dlogp(q, gp.lml_grad, jacobian=False), model.initial_point(), maxeval=40)
 t0 = time.perf_counter()
 r = sample_chain(f, qmap, draws=30, tune=30, seed=0)
 dt = time.perf_counter() - t0

@@ -96,6 +96,7 @@ class MiGP:
         """LML at natural-scale theta; -inf if K is not positive definite (info > 0)."""
         theta, tp = self._theta(theta)
         out = ctypes.c_double()
+        self._factored_ok = False
         self.info = self._check(self.lib.mi_gp_lml(self.h, tp, ctypes.byref(out)), "mi_gp_lml")
         return out.value
 
@@ -112,6 +113,7 @@ class MiGP:
         out = ctypes.c_double()
         grad = np.zeros(self.ntheta)
         gp_ = grad.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+        self._factored_ok = False
         self.info = self._check(self.lib.mi_gp_lml_grad(self.h, tp, ctypes.byref(out), gp_), "mi_gp_lml_grad")
         return out.value, grad
 
@@ -136,6 +138,7 @@ class MiGP:
     def update_data(self, X=None, y=None):
         """Overwrite the resident inputs / outputs in place (same shapes): warped data change at every
         posterior evaluation while the buffers, the handle and its captured graphs stay."""
+        self._factored_ok = False
         with torch.cuda.device(self.dev):
             if X is not None:
                 X = np.ascontiguousarray(X, dtype=np.float64)
@@ -151,6 +154,7 @@ class MiGP:
 
     def set_diag(self, diag=None):
         """Per-point diagonal added to K at assembly (None removes it)."""
+        self._factored_ok = False
         with torch.cuda.device(self.dev):
             if diag is None:
                 self._diag_t = None
@@ -197,6 +201,35 @@ class MiGP:
                 mean[s : s + mc] = mu_t.cpu().numpy()
                 var[s : s + mc] = var_t.cpu().numpy()
         return mean, var
+
+    def predict_grad(self, theta, Xnew, pred_noise=True, refactor=True):
+        """Posterior mean / variance at a few points and their gradients w.r.t. the points:
+        (mean[m], var[m], dmean[m,d], dvar[m,d]).  ``refactor=False`` reuses the resident factorisation
+        (same theta as the previous predict / predict_grad call)."""
+        if self.Z_t is None:
+            raise RuntimeError("this MiGP was created with need_grad=False")
+        if refactor or not getattr(self, "_factored_ok", False):
+            if self.factor(theta) != 0:
+                raise FloatingPointError(f"covariance not positive definite at pivot {self.info}")
+            self._factored_ok = True
+        Xnew = np.ascontiguousarray(Xnew, dtype=np.float64)
+        if Xnew.ndim != 2 or Xnew.shape[1] != self.d:
+            raise ValueError("Xnew must be (m, d)")
+        m = Xnew.shape[0]
+        mp = (m + 127) // 128 * 128
+        with torch.cuda.device(self.dev):
+            if getattr(self, "_work2", None) is None or self._work2.shape[0] < 2 * mp:
+                self._work2 = torch.empty((2 * mp, self.lda), dtype=torch.float64, device=self.dev)
+            xn = torch.from_numpy(Xnew).to(self.dev)
+            out = torch.empty((2 * m + 2 * m * self.d,), dtype=torch.float64, device=self.dev)
+            torch.cuda.synchronize(self.dev)
+            mu_p, var_p = out.data_ptr(), out.data_ptr() + 8 * m
+            dmu_p, dvar_p = out.data_ptr() + 16 * m, out.data_ptr() + 16 * m + 8 * m * self.d
+            self._check(self.lib.mi_gp_predict_grad(self.h, xn.data_ptr(), m, self._work2.data_ptr(), self.lda, mu_p, var_p,
+                                                    1 if pred_noise else 0, dmu_p, dvar_p), "mi_gp_predict_grad")
+            o = out.cpu().numpy()
+        return (o[:m], o[m : 2 * m], o[2 * m : 2 * m + m * self.d].reshape(m, self.d),
+                o[2 * m + m * self.d :].reshape(m, self.d))
 
     def set_option(self, what, value):
         """0: look-ahead on/off, 1: GEMM variant, 2: super-panel width (tiles)."""

@@ -51,6 +51,7 @@ struct mi_gp_handle {
   double t_trtri_ms, t_lauum_ms, t_contract_ms;
   double t_gemm_big_ms, gemm_big_flops, n_gemm_big;  // the 128x128-tile kernel only
   bool factored;
+  bool have_u;             // Z_dev holds U = L^-T and alpha_dev = K^-1 y of the last mi_gp_factor (mi_gp_predict_grad)
   bool have_kinv;          // W_dev holds K^-1 (lower) and alpha_dev = K^-1 y of the last mi_gp_lml_grad
   const double* diag_dev;  // optional per-point diagonal added at assembly (mi_gp_set_diag)
   char err[256];
@@ -90,6 +91,7 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   h->have_data = false;
   h->factored = false;
   h->have_kinv = false;
+  h->have_u = false;
   h->diag_dev = nullptr;
   h->t_trtri_ms = h->t_lauum_ms = h->t_contract_ms = 0.0;
   h->t_gemm_big_ms = h->gemm_big_flops = h->n_gemm_big = 0.0;
@@ -398,6 +400,7 @@ static int run_evaluation(mi_gp_handle* h, int what) {
 static int factor_internal(mi_gp_handle* h, const double* theta, int what) {
   h->factored = false;
   h->have_kinv = false;
+  h->have_u = false;
   if (!h->have_data) { snprintf(h->err, sizeof(h->err), "mi_gp_set_data has not been called"); return -1; }
   HCK(hipSetDevice(h->device), "hipSetDevice");
   for (int i = 0; i < h->ntheta; ++i) {
@@ -630,6 +633,37 @@ extern "C" int mi_gp_predict(mi_gp_handle* h, const double* Xnew_dev, int m, dou
   const double sg = std::sqrt(th[nk * d + 2 * nk]);
   HCK(launch_predict_reduce(work_dev, ldw, h->buf.K_dev + (long)h->np * h->buf.lda, h->n, m, kd,
                             pred_noise ? sg * sg : 0.0, mean_dev, var_dev, h->stream), "predict_reduce");
+  HCK(hipStreamSynchronize(h->stream), "stream sync");
+  return 0;
+}
+
+// Posterior mean / variance at m points AND their gradients w.r.t. the (converted) points: the differentiable
+// predictive of BO's refinement (gpmcmc.py:766-801).  Needs Z_dev / W_dev (U = L^-T is formed once per
+// mi_gp_factor, N^3/3 flops on the GEMM kernel) and work_dev with 2 * ceil(m/128)*128 rows: the second half
+// receives w_p = K^-1 k(X, x*_p) = U (L^-1 k*_p), one row per point.
+extern "C" int mi_gp_predict_grad(mi_gp_handle* h, const double* Xnew_dev, int m, double* work_dev, long ldw,
+                                  double* mean_dev, double* var_dev, int pred_noise, double* dmean_dev,
+                                  double* dvar_dev) {
+  if (!h || !dmean_dev || !dvar_dev) return -1;
+  if (!h->buf.Z_dev || !h->buf.W_dev) {
+    snprintf(h->err, sizeof(h->err), "mi_gp_predict_grad needs Z_dev and W_dev in mi_gp_set_data");
+    return -1;
+  }
+  if (h->cfg.d > 128) { snprintf(h->err, sizeof(h->err), "mi_gp_predict_grad: d <= 128"); return -1; }
+  const int r = mi_gp_predict(h, Xnew_dev, m, work_dev, ldw, mean_dev, var_dev, pred_noise);
+  if (r != 0) return r;
+  const long ld = h->buf.lda;
+  if (!h->have_u) {
+    HCK(inverse_transpose(h), "inverse_transpose");
+    HCK(launch_trmv_upper(h->buf.Z_dev, ld, h->buf.K_dev + (long)h->np * ld, h->n, h->alpha_dev, h->stream), "trmv");
+    h->have_u = true;
+  }
+  const int mp = (m + 127) / 128 * 128;
+  double* wrows = work_dev + (long)mp * ldw;
+  for (int p = 0; p < m; ++p)
+    HCK(launch_trmv_upper(h->buf.Z_dev, ld, work_dev + (long)p * ldw, h->n, wrows + (long)p * ldw, h->stream), "trmv w");
+  HCK(launch_predict_grad(h->spec, h->theta_dev, h->buf.X_dev, h->n, Xnew_dev, m, h->alpha_dev, wrows, ldw, dmean_dev,
+                          dvar_dev, h->stream), "predict_grad");
   HCK(hipStreamSynchronize(h->stream), "stream sync");
   return 0;
 }

@@ -528,6 +528,110 @@ hipError_t launch_grad_contract(const KernSpec& spec, const double* theta, const
   return hipGetLastError();
 }
 
+// Gradient of the posterior conditional w.r.t. ONE prediction point x* (converted inputs):
+//   d mu / d x*_m  =  sum_i alpha_i dk(x_i, x*)/dx*_m,     d var / d x*_m = -2 sum_i w_i dk(x_i, x*)/dx*_m,
+// with alpha = K^-1 y, w = K^-1 k(X, x*) and dk/dx*_m = sum_c coef_c kv_c k_c'(r2_c) 2 (x*_m - x_im) / l_cm^2
+// (Stationary.diag is constant, so the prior variance does not move).  This is the differentiable single-point
+// predictive that BO's refinement step builds in PyTensor at gpmcmc.py:766-778 and maximises with pm.find_MAP.
+// One workgroup per point; dimensions in chunks of 16 held in registers, block-reduced through LDS.
+template <int NK>
+__global__ __launch_bounds__(256) void predict_grad_kernel(KernSpec spec, const double* __restrict__ theta,
+                                                           const double* __restrict__ X, int n,
+                                                           const double* __restrict__ xstar,
+                                                           const double* __restrict__ alpha_v,
+                                                           const double* __restrict__ wv, long ldwv,
+                                                           double* __restrict__ dmean, double* __restrict__ dvar) {
+  __shared__ double xs[GX_MAXD];
+  __shared__ double ils[NK * GX_MAXD];
+  __shared__ double red[2][GXCH][4];
+  const int tid = threadIdx.x;
+  const int d = spec.d;
+  const int p = blockIdx.x;
+  const double* kv = theta + NK * d;
+  const double* al = kv + NK;
+  const double* w = wv + (long)p * ldwv;
+  for (int e = tid; e < d; e += 256) xs[e] = xstar[(long)p * d + e];
+  for (int e = tid; e < NK * d; e += 256) ils[(e / d) * GX_MAXD + e % d] = 1.0 / theta[e];
+  __syncthreads();
+  for (int m0 = 0; m0 < d; m0 += GXCH) {
+    const int dc = min(GXCH, d - m0);
+    double am[GXCH], av[GXCH];
+#pragma unroll
+    for (int u = 0; u < GXCH; ++u) am[u] = av[u] = 0.0;
+    for (int i = tid; i < n; i += 256) {
+      const double* xi = X + (long)i * d;
+      double kval[NK], dkv[NK];
+#pragma unroll
+      for (int c = 0; c < NK; ++c) {
+        double r2 = 0.0;
+        for (int m = 0; m < d; ++m) {
+          const double df = (xs[m] - xi[m]) * ils[c * GX_MAXD + m];
+          r2 += df * df;
+        }
+        double k, dk, da;
+        base_kernel_val_der(spec.kid[c], r2, al[c], k, dk, da);
+        kval[c] = kv[c] * k;
+        dkv[c] = kv[c] * dk;
+      }
+      double pref[NK];
+      double T = kval[0];
+      pref[0] = 1.0;
+#pragma unroll
+      for (int c = 1; c < NK; ++c) {
+        pref[c] = (spec.op[c - 1] == 0) ? 1.0 : T;
+        T = (spec.op[c - 1] == 0) ? T + kval[c] : T * kval[c];
+      }
+      const double ai = alpha_v[i], wi = -2.0 * w[i];
+#pragma unroll
+      for (int c = 0; c < NK; ++c) {
+        double coef = pref[c];
+#pragma unroll
+        for (int c2 = c + 1; c2 < NK; ++c2)
+          if (spec.op[c2 - 1] == 1) coef *= kval[c2];
+        const double g = coef * dkv[c];
+#pragma unroll
+        for (int u = 0; u < GXCH; ++u) {
+          if (u < dc) {
+            const double il = ils[c * GX_MAXD + m0 + u];
+            const double dkx = g * 2.0 * (xs[m0 + u] - xi[m0 + u]) * il * il;
+            am[u] += ai * dkx;
+            av[u] += wi * dkx;
+          }
+        }
+      }
+    }
+    // fixed-order block reduction: wave shuffle, then the four wave sums
+#pragma unroll
+    for (int u = 0; u < GXCH; ++u) {
+      double a = am[u], b = av[u];
+      for (int off = 32; off > 0; off >>= 1) {
+        a += __shfl_down(a, off, 64);
+        b += __shfl_down(b, off, 64);
+      }
+      if ((tid & 63) == 0) { red[0][u][tid >> 6] = a; red[1][u][tid >> 6] = b; }
+    }
+    __syncthreads();
+    if (tid < dc) {
+      dmean[(long)p * d + m0 + tid] = red[0][tid][0] + red[0][tid][1] + red[0][tid][2] + red[0][tid][3];
+      dvar[(long)p * d + m0 + tid] = red[1][tid][0] + red[1][tid][1] + red[1][tid][2] + red[1][tid][3];
+    }
+    __syncthreads();
+  }
+}
+
+hipError_t launch_predict_grad(const KernSpec& spec, const double* theta, const double* X, int n, const double* xstar,
+                               int m, const double* alpha, const double* w, long ldw, double* dmean, double* dvar,
+                               hipStream_t stream) {
+  if (spec.d > GX_MAXD) return hipErrorInvalidValue;
+  switch (spec.nkern) {
+    case 1: predict_grad_kernel<1><<<m, 256, 0, stream>>>(spec, theta, X, n, xstar, alpha, w, ldw, dmean, dvar); break;
+    case 2: predict_grad_kernel<2><<<m, 256, 0, stream>>>(spec, theta, X, n, xstar, alpha, w, ldw, dmean, dvar); break;
+    case 3: predict_grad_kernel<3><<<m, 256, 0, stream>>>(spec, theta, X, n, xstar, alpha, w, ldw, dmean, dvar); break;
+    default: predict_grad_kernel<4><<<m, 256, 0, stream>>>(spec, theta, X, n, xstar, alpha, w, ldw, dmean, dvar); break;
+  }
+  return hipGetLastError();
+}
+
 hipError_t launch_grad_x(const KernSpec& spec, const double* theta, const double* X, int n, const double* W, long ldw,
                          const double* alpha, double* gx, hipStream_t stream) {
   if (spec.d > GX_MAXD) return hipErrorInvalidValue;

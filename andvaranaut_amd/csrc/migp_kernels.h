@@ -70,6 +70,10 @@ hipError_t launch_grad_contract(const KernSpec& spec, const double* theta, const
 // gx: [n][d] dLML/dX from Kinv (lower triangle in W) and alpha; d <= 128
 hipError_t launch_grad_x(const KernSpec& spec, const double* theta, const double* X, int n, const double* W, long ldw,
                          const double* alpha, double* gx, hipStream_t stream);
+// dmean/dvar: [m][d] gradients of the conditional at m points; w: row p = K^-1 k(X, x*_p) (leading dimension ldw)
+hipError_t launch_predict_grad(const KernSpec& spec, const double* theta, const double* X, int n, const double* xstar,
+                               int m, const double* alpha, const double* w, long ldw, double* dmean, double* dvar,
+                               hipStream_t stream);
 hipError_t launch_predict_reduce(const double* A, long lda, const double* beta, int n, int m, double kdiag,
                                  double noise, double* mean, double* var, hipStream_t stream);
 

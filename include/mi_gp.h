@@ -97,6 +97,12 @@ int mi_gp_factor(mi_gp_handle* h, const double* theta_host);
  * ceil(m/128)*128 rows x ldw (ldw even, >= mi_gp_padded_n()); mean_dev / var_dev receive m doubles. */
 int mi_gp_predict(mi_gp_handle* h, const double* Xnew_dev, int m, double* work_dev, long ldw, double* mean_dev,
                   double* var_dev, int pred_noise);
+/* The same plus d mu / d x* and d var / d x* (m x d each, device): d mu = sum_i alpha_i dk(x_i,x*)/dx*,
+ * d var = -2 sum_i w_i dk(x_i,x*)/dx* with w = K^-1 k(X,x*).  Replaces the PyTensor graph of the single-point
+ * predictive that BO's refinement differentiates (gpmcmc.py:766-801).  Needs Z_dev / W_dev; work_dev must hold
+ * 2 * ceil(m/128)*128 rows x ldw (the upper half receives the w rows); d <= 128. */
+int mi_gp_predict_grad(mi_gp_handle* h, const double* Xnew_dev, int m, double* work_dev, long ldw, double* mean_dev,
+                       double* var_dev, int pred_noise, double* dmean_dev, double* dvar_dev);
 
 /* tuning knobs (benchmarks / A-B tests): what = 0 one-super-panel look-ahead on the second stream
  * (per handle, default 1); 1 GEMM kernel variant (process-wide: 0 = 8 waves, 1 workgroup per CU;

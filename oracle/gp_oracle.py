@@ -294,6 +294,44 @@ def predict(X, y, Xnew, kerns, ops, theta, pred_noise=True):
 
 
 # ---------------------------------------------------------- synthetic workloads
+def predict_grad(X, y, Xnew, kerns, ops, theta):
+    """Gradients of the conditional mean / variance w.r.t. each prediction point (converted inputs):
+    d mu/dx* = sum_i alpha_i dk(x_i,x*)/dx*,  d var/dx* = -2 sum_i w_i dk(x_i,x*)/dx*,  w = K^-1 k(X,x*).
+    The reference differentiates the same single-point predictive by PyTensor autodiff (gpmcmc.py:766-801)."""
+    d = X.shape[1]
+    nk = len(kerns)
+    ls, kv, alpha, gv, jitter = split_theta(theta, d, nk)
+    K = noisy_cov(X, kerns, ops, theta, form="conditional")
+    L = sla.cholesky(K, lower=True)
+    a = sla.cho_solve((L, True), y)
+    M = Xnew.shape[0]
+    dmu, dvar = np.zeros((M, d)), np.zeros((M, d))
+    for p in range(M):
+        xs = Xnew[p : p + 1]
+        comps, r2s = component_matrices(X, xs, kerns, ls, kv, alpha)  # n x 1 each
+        kstar = combine(comps, ops)[:, 0]
+        w = sla.cho_solve((L, True), kstar)
+        pref = [None] * nk
+        T = comps[0]
+        pref[0] = np.ones_like(T)
+        for i in range(1, nk):
+            pref[i] = np.ones_like(T) if ops[i - 1] == "+" else T.copy()
+            T = T + comps[i] if ops[i - 1] == "+" else T * comps[i]
+        for c in range(nk):
+            coef = pref[c]
+            for i in range(c + 1, nk):
+                if ops[i - 1] == "*":
+                    coef = coef * comps[i]
+            dk = kv[c] * base_kernel_dr2(kerns[c], r2s[c], alpha[c])
+            dk = np.where(r2s[c] > 0.0, dk, 0.0)
+            g = (coef * dk)[:, 0]
+            for m in range(d):
+                dkx = g * 2.0 * (xs[0, m] - X[:, m]) / ls[c, m] ** 2
+                dmu[p, m] += a @ dkx
+                dvar[p, m] += -2.0 * (w @ dkx)
+    return dmu, dvar
+
+
 def synth_problem(N, d, seed=0):
     """SURVEY.md section 8d inputs: LHS in [0,1]^d (mirrors lhc.py:42-43), standardised
     y = sin(3 sum x) + sum x^2/d + N(0,1e-4)."""

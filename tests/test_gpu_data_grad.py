@@ -124,3 +124,36 @@ def test_data_gradients_need_a_gradient_evaluation_first():
     r = gp.lib.mi_gp_alpha(gp.h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
     assert r == -1 and b"mi_gp_lml_grad" in gp.lib.mi_gp_last_error(gp.h)
     gp.close()
+
+
+PG_CASES = [(1, 1, "RBF", 1), (50, 2, "Matern52", 3), (129, 3, "Matern32", 1), (700, 16, "Matern52", 5),
+            (640, 5, "RBF*Matern52", 2), (900, 2, "RBF+Matern52*Exponential", 4), (300, 3, "RatQuad", 130),
+            (2000, 33, "RBF", 2)]
+
+
+@pytest.mark.parametrize("N,d,kernel,M", PG_CASES)
+def test_predictive_gradients_match_oracle(N, d, kernel, M):
+    """mi_gp_predict_grad: the differentiable single-point predictive of BO's refinement (gpmcmc.py:766-801)."""
+    MiGP, orc = _mods()
+    X, y = orc.synth_problem(max(N, 3), d, seed=N + 7 * d)
+    X, y = X[:N], y[:N]
+    kerns, ops = _split(kernel)
+    theta = orc.synth_theta(d, nkern=len(kerns), gv=1e-3)
+    Xn = np.random.default_rng(M).uniform(0.05, 0.95, (M, d))
+    gp = MiGP(X, y, kernel)
+    mu, var, dmu, dvar = gp.predict_grad(theta, Xn)
+    mu_o, var_o = orc.predict(X, y, Xn, kerns, ops, theta)
+    dmu_o, dvar_o = orc.predict_grad(X, y, Xn, kerns, ops, theta)
+    assert np.allclose(mu, mu_o, rtol=1e-7, atol=1e-9) and np.allclose(var, var_o, rtol=1e-6, atol=1e-10)
+    tol = 1e-5 if "Exponential" in kernel else 1e-7
+    assert np.abs(dmu - dmu_o).max() <= tol * max(np.abs(dmu_o).max(), 1e-300)
+    assert np.abs(dvar - dvar_o).max() <= tol * max(np.abs(dvar_o).max(), 1e-300)
+    # a second call on the resident factorisation (other points) gives the same answers as a fresh one
+    Xn2 = Xn[::-1].copy()
+    _, _, dmu2, dvar2 = gp.predict_grad(theta, Xn2, refactor=False)
+    assert np.allclose(dmu2, dmu[::-1], rtol=1e-12, atol=0) and np.allclose(dvar2, dvar[::-1], rtol=1e-12, atol=0)
+    # and an LML evaluation in between does not leave a stale inverse behind
+    gp.lml(theta)
+    _, _, dmu3, _ = gp.predict_grad(theta, Xn)
+    assert np.allclose(dmu3, dmu, rtol=1e-12, atol=0)
+    gp.close()

@@ -170,13 +170,24 @@ class MiGP:
     def factor(self, theta):
         """Factorise for prediction (conditional form); returns LAPACK-style info."""
         theta, tp = self._theta(theta)
+        self._factored_ok = False
         self.info = self._check(self.lib.mi_gp_factor(self.h, tp), "mi_gp_factor")
+        if self.info == 0:
+            self._factored_ok, self._factored_theta = True, theta.copy()
         return self.info
+
+    def _ensure_factored(self, theta):
+        """Factorise unless the resident factor already belongs to this theta (BO sweeps, DE populations and
+        refinement steps predict thousands of times at fixed hyper-parameters)."""
+        theta = np.ascontiguousarray(theta, dtype=np.float64)
+        if getattr(self, "_factored_ok", False) and np.array_equal(theta, self._factored_theta):
+            return
+        if self.factor(theta) != 0:
+            raise FloatingPointError(f"covariance not positive definite at pivot {self.info}")
 
     def predict(self, theta, Xnew, pred_noise=True, chunk=16384):
         """Posterior mean and diagonal variance at Xnew (converted inputs), chunked over points."""
-        if self.factor(theta) != 0:
-            raise FloatingPointError(f"covariance not positive definite at pivot {self.info}")
+        self._ensure_factored(theta)
         Xnew = np.ascontiguousarray(Xnew, dtype=np.float64)
         if Xnew.ndim != 2 or Xnew.shape[1] != self.d:
             raise ValueError("Xnew must be (m, d)")
@@ -208,10 +219,9 @@ class MiGP:
         (same theta as the previous predict / predict_grad call)."""
         if self.Z_t is None:
             raise RuntimeError("this MiGP was created with need_grad=False")
-        if refactor or not getattr(self, "_factored_ok", False):
-            if self.factor(theta) != 0:
-                raise FloatingPointError(f"covariance not positive definite at pivot {self.info}")
-            self._factored_ok = True
+        if refactor:
+            self._factored_ok = False
+        self._ensure_factored(theta)
         Xnew = np.ascontiguousarray(Xnew, dtype=np.float64)
         if Xnew.ndim != 2 or Xnew.shape[1] != self.d:
             raise ValueError("Xnew must be (m, d)")

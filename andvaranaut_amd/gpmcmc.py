@@ -7,7 +7,8 @@ same ``hypers`` dictionary keys as the reference (gpmcmc.py:31-32,122,158,175-17
 keys recorded at tutorial/tutorial.ipynb:529), including the warped fits ``fit(iwgp=True)`` /
 ``fit(cwgp=True)`` whose warp parameters are optimised / sampled with the hyper-parameters
 (gpmcmc.py:211-279,319): the device supplies dLML/dX and dLML/dy, torch.autograd carries them through the
-warps.  Out of scope here: dask-parallel target execution, plots."""
+warps.  ``BO`` and ``inverse_opt`` live in consumers.py.  Out of scope here:
+dask-parallel target execution, plots."""
 import copy
 import os
 import re
@@ -17,6 +18,7 @@ from time import time as stopwatch
 import numpy as np
 
 from .backend import MiGP, parse_kernel
+from .consumers import ConsumersMixin
 from .lhc import latin_sample
 from .nuts import Trace, sample_chain
 from .optimize import find_MAP
@@ -24,7 +26,7 @@ from .priors import HyperModel
 from .transform import _none_conrev, wgp
 
 
-class GPMCMC:
+class GPMCMC(ConsumersMixin):
     def __init__(self, xconrevs=None, yconrevs=None, kernel="RBF", noise=True, mean=0, nx=None, ny=None,
                  priors=None, target=None, parallel=False, nproc=1, constraints=None, rundir=None, verbose=True,
                  pulse=1, device=0):
@@ -318,7 +320,10 @@ class GPMCMC:
                 # the reference builds a random start and never passes it (gpmcmc.py:330-332): every
                 # restart begins at the model's initial point, so they coincide; kept as is
                 try:
-                    q, info = find_MAP(fun_map, model.initial_point(), progressbar=kwargs.get("progressbar", False),
+                    q0 = model.initial_point()
+                    if kwargs.get("start") is not None:  # pm.find_MAP(start=...), e.g. BO's warm refits (gpmcmc.py:899)
+                        q0 = model.q_from_point(kwargs["start"])
+                    q, info = find_MAP(fun_map, q0, progressbar=kwargs.get("progressbar", False),
                                        maxeval=kwargs.get("maxeval", 5000))
                 except Exception:
                     print("Restart failed")

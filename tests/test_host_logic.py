@@ -289,3 +289,40 @@ def test_find_map_objective_has_no_transform_jacobian():
     b, gb = model.logp_dlogp(q, cb, jacobian=False)
     assert abs((a - b) - np.sum(q)) < 1e-9  # all three blocks are log-transformed: log|dx/dq| = q
     assert np.allclose(ga - gb, 1.0)
+
+
+def test_input_model_priors_and_gradient():
+    """scipy -> PyMC prior conversion of BO / inverse_opt (gpmcmc.py:702-728,1053-1094) and the transformed
+    log-density that find_MAP / NUTS see."""
+    from andvaranaut_amd.consumers import InputModel, Uniform, pymc_prior
+    from andvaranaut_amd.priors import Normal, TruncatedNormal
+
+    u = pymc_prior(st.uniform(loc=1, scale=0.5))
+    assert isinstance(u, Uniform) and (u.lower, u.upper) == (1.0, 1.5)
+    u2 = pymc_prior(st.uniform(2.0, 3.0))
+    assert (u2.lower, u2.upper) == (2.0, 5.0)
+    nrm = pymc_prior(st.norm(loc=0.3, scale=2.0))
+    assert isinstance(nrm, Normal) and (nrm.mu, nrm.sigma) == (0.3, 2.0)
+    t = pymc_prior(st.truncnorm(-1.0, 2.0, loc=0.5, scale=0.2), allow_truncnorm=True)
+    assert isinstance(t, TruncatedNormal) and np.allclose([t.lower, t.upper, t.mu, t.sigma], [0.3, 0.9, 0.5, 0.2])
+    with pytest.raises(Exception):
+        pymc_prior(st.truncnorm(-1.0, 2.0))  # BO converts uniform and normal priors only
+    with pytest.raises(Exception):
+        pymc_prior(st.beta(2, 3), allow_truncnorm=True)
+    im = InputModel([u, nrm, t])
+    pot = lambda x: (-np.sum((x - np.array([1.2, 0.1, 0.6])) ** 2), -2 * (x - np.array([1.2, 0.1, 0.6])))  # noqa: E731
+    q = im.initial_point() + np.array([0.3, -0.2, 0.4])
+    for jac in (True, False):
+        v, g = im.logp_dlogp(q, pot, jacobian=jac)
+        for i in range(3):
+            h = 1e-6
+            qp, qm = q.copy(), q.copy()
+            qp[i] += h
+            qm[i] -= h
+            fd = (im.logp_dlogp(qp, pot, jacobian=jac)[0] - im.logp_dlogp(qm, pot, jacobian=jac)[0]) / (2 * h)
+            assert abs(fd - g[i]) < 1e-6 * max(1.0, abs(fd))
+    pt = im.point_dict(q)
+    assert set(pt) == {"x0_interval__", "x0", "x1", "x2_interval__", "x2"}
+    assert np.allclose(im.q_from_x(im.x_from_q(q)), q)
+    # truncated-normal logp against scipy
+    assert abs(float(t.logp(np.array(0.55))) - st.truncnorm(-1.0, 2.0, loc=0.5, scale=0.2).logpdf(0.55)) < 1e-12

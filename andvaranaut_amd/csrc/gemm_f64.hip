@@ -552,16 +552,23 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel_s(GemmParams p) {
       vs::chunk_load(Ag, gA, sA, ra);
       vs::chunk_load(Bg, gB, sB, rb);
     }
+    // all 16 fragment reads of the chunk first, then its 16 MFMAs: one exposed LDS latency per chunk, not four
+    double fa[BKS / 4][2], fb[BKS / 4][2];
 #pragma unroll
     for (int kk = 0; kk < BKS / 4; ++kk) {
       const double* ap = a_ptr + boff + kk * 4 * LDS_S;
       const double* bp = b_ptr + boff + kk * 4 * LDS_S;
-      const double a0 = ap[0], a1 = ap[16], b0 = bp[0], b1 = bp[16];
-      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+      fa[kk][0] = ap[0]; fa[kk][1] = ap[16]; fb[kk][0] = bp[0]; fb[kk][1] = bp[16];
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < BKS / 4; ++kk) {
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[kk][0], fb[kk][0], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[kk][0], fb[kk][1], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[kk][1], fb[kk][0], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[kk][1], fb[kk][1], acc[1][1], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     if (more) {
       const int noff = (boff ^ OPER_S) * 8;
       vs::chunk_store<A_KMAJOR>(Asb + noff, lA, ra);

@@ -1,4 +1,4 @@
-"""A/B: split panel chain (option 9) with graph on/off; also checks bit-identical LML."""
+"""A/B: in-panel updates inside the next leaf's launch (option 9) with graph on/off; checks bit-identical LML."""
 import sys, time, os
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -14,7 +14,6 @@ for N in (1000, 4096, 8192, 16384):
     for rnd in range(3):
         for graph in (0, 1):
             for split in (0, 1):
-                if graph and split: continue
                 gp.set_option(3, graph); gp.set_option(9, split)
                 v = gp.lml(theta); v = gp.lml(theta)
                 vals[(graph, split)] = v

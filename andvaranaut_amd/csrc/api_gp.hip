@@ -22,6 +22,7 @@ struct mi_gp_handle {
   hipEvent_t ev_panel, ev_upd;
   int lookahead;
   int use_graph;
+  int bulk_wide;   // look-ahead bulk updates on the 8-wave / one-workgroup-per-CU GEMM kernel (variant C)
   int lowocc_thr;  // trailing sizes (tile columns) at or below which bulk updates run one workgroup per CU
   int w_thr[3];  // trailing sizes (tile columns) above which the super-panel is 16 / 8 / 4 tiles wide
   std::map<int, hipGraphExec_t> graphs;  // captured evaluation DAGs, keyed by (what, options)
@@ -108,6 +109,7 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_upd, hipEventDisableTiming);
   h->lookahead = 1;
   h->use_graph = 1;
+  h->bulk_wide = 0;
   h->lowocc_thr = 64;
   h->w_thr[0] = 1 << 20; h->w_thr[1] = 72; h->w_thr[2] = 0;
   if (e == hipSuccess) e = hipMalloc(&h->theta_dev, sizeof(double) * h->ntheta);
@@ -179,6 +181,7 @@ extern "C" int mi_gp_set_option(mi_gp_handle* h, int what, int value) {
   else if (what >= 4 && what <= 6) h->w_thr[what - 4] = value;
   else if (what == 7) set_gemm_small_tiles(value);
   else if (what == 8) h->lowocc_thr = value;
+  else if (what == 9) h->bulk_wide = value ? 1 : 0;
   else return -1;
   return 0;
 }
@@ -217,9 +220,10 @@ static hipError_t prof_gemm(mi_gp_handle* h, const GemmParams& p, int ak, int bk
 
 // trapezoid update  A[r0:, c0:c0+nc] -= P P_c^T  with P = A[r0:, k0:k0+kw] (tile units)
 static hipError_t syrk_trapezoid(mi_gp_handle* h, double* A, long lda, int ntr, int r0, int nc, int k0, int kw,
-                                 hipStream_t st, int one_per_cu = 0) {
+                                 hipStream_t st, int one_per_cu = 0, int wide8 = 0) {
   GemmParams p;
   p.one_per_cu = one_per_cu;
+  p.wide8 = wide8;
   p.A = A + (long)r0 * 128 * lda + (long)k0 * 128;
   p.B = p.A;
   p.C = A + (long)r0 * 128 * lda + (long)r0 * 128;
@@ -297,7 +301,10 @@ static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int nt
     }
     CKE(chol_panel(h, A, lda, ntr, n1, wn, P));
     // (b) the rest of the trailing matrix, concurrently with that panel factorisation
-    if (n1 + wn < ntc) CKE(syrk_trapezoid(h, A, lda, ntr, n1 + wn, ntc - n1 - wn, J, w, T, (P != T && ntc - n1 <= h->lowocc_thr) ? 1 : 0));
+    // (b) runs next to the panel chain: the 8-wave kernel leaves half of every CU to it
+    if (n1 + wn < ntc)
+      CKE(syrk_trapezoid(h, A, lda, ntr, n1 + wn, ntc - n1 - wn, J, w, T,
+                         (P != T && !h->bulk_wide && ntc - n1 <= h->lowocc_thr) ? 1 : 0, (P != T && h->bulk_wide) ? 1 : 0));
     J = n1;
     w = wn;
   }
@@ -347,7 +354,7 @@ static int run_evaluation(mi_gp_handle* h, int what) {
     if (what == 2) { if (int r = enqueue_gradient(h, prof)) return r; }
     return download_results(h, what);
   }
-  const int key = what | (h->lookahead << 4) | ((h->cfg.panel_tiles & 0xff) << 8) | (gemm_variant_get() << 20) |
+  const int key = what | (h->lookahead << 4) | (h->bulk_wide << 5) | ((h->cfg.panel_tiles & 0xff) << 8) | (gemm_variant_get() << 20) |
                   ((h->w_thr[0] * 31 + h->w_thr[1] * 7 + h->w_thr[2] + h->lowocc_thr * 13) & 0x7ff) << 21;
   auto it = h->graphs.find(key);
   if (it == h->graphs.end()) {

@@ -464,6 +464,227 @@ __global__ __launch_bounds__(vb::NT_B, 2) void gemm_f64_kernel_b(GemmParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Variant C (option, off by default: mi_gp_set_option(h, 9, 1)): one 512-thread workgroup per CU (8 waves as 2x4,
+// 64x32 outputs per wave = 4x2 MFMA tiles, 32 accumulator doubles per lane), K chunks of 16, the same 72 KiB LDS
+// image and the same interleaved, branch-free schedule as variant B -- but 142 VGPRs and half a CU's LDS, so that
+// every CU keeps room for one workgroup of the panel chain while a look-ahead trailing update runs.  Stand-alone
+// it reaches 73.0 TFLOP/s on 8192^3 (B: 75.5) and 66.8 on the k=1024 trapezoid (B: 69.1).  As the look-ahead bulk
+// kernel it changes nothing (N=16384: 30.8 vs 30.7 ms): the chain's kernels do find a slot at once, but next to
+// MFMA-saturated waves they still run 1.7-2.2x slower than alone (leaf 75 us vs 34) -- it is execution
+// contention on the CU, not waiting for a free slot, that stretches the panel stream.  Kept as the building
+// block for a CU-partitioned (persistent) trailing update.
+namespace vc {
+constexpr int BKC = 16;
+constexpr int OPER_C = BKC * LDS_LD;
+constexpr int NT_C = 512;
+constexpr int NQC = TILE * BKC / 2 / NT_C;  // 2
+
+template <bool KMAJOR>
+__device__ __forceinline__ void chunk_offsets(long ld, int tid, unsigned& goff, unsigned& loff, long& gstride) {
+  if (KMAJOR) {
+    const int k = tid >> 6, xc = tid & 63;  // k = 8q + (t>>6)
+    goff = (unsigned)((k * ld + 2 * xc) * 8);
+    loff = (unsigned)((k * LDS_LD + 2 * xc) * 8);
+    gstride = 8 * ld * 8;
+  } else {
+    const int xl = tid & 15, kc = (tid >> 4) & 7, xh = tid >> 7;  // x = 64q + 16*(t>>7) + (t&15)
+    goff = (unsigned)(((xh * 16 + xl) * ld + 2 * kc) * 8);
+    loff = (unsigned)(((2 * kc) * LDS_LD + xh * 16 + xl) * 8);
+    gstride = 64 * ld * 8;
+  }
+}
+__device__ __forceinline__ void chunk_load(const char* __restrict__ base, unsigned goff, long gstride,
+                                           double2_t (&r)[NQC]) {
+#pragma unroll
+  for (int q = 0; q < NQC; ++q) r[q] = *reinterpret_cast<const double2_t*>(base + q * gstride + goff);
+}
+template <bool KMAJOR>
+__device__ __forceinline__ void chunk_store(char* __restrict__ lds, unsigned loff, const double2_t (&r)[NQC]) {
+#pragma unroll
+  for (int q = 0; q < NQC; ++q) {
+    if (KMAJOR) {
+      *reinterpret_cast<double2_t*>(lds + loff + q * (8 * LDS_LD * 8)) = r[q];
+    } else {
+      *reinterpret_cast<double*>(lds + loff + q * (64 * 8)) = r[q].x;
+      *reinterpret_cast<double*>(lds + loff + q * (64 * 8) + LDS_LD * 8) = r[q].y;
+    }
+  }
+}
+}  // namespace vc
+
+template <bool A_KMAJOR, bool B_KMAJOR>
+__global__ __launch_bounds__(vc::NT_C, 1) void gemm_f64_kernel_c(GemmParams p) {
+  using vc::BKC; using vc::OPER_C; using vc::NQC;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* As = smem;               // [2][BKC][LDS_LD]
+  double* Bs = smem + 2 * OPER_C;  // [2][BKC][LDS_LD]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+
+  const int nblk = gridDim.x;
+  int idx = blockIdx.x;
+  if (p.kmode == 0) {
+    const int b = blockIdx.x, x = b & 7, q = nblk >> 3, r = nblk & 7;
+    idx = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+  }
+  int ti, tj;
+  tile_from_index(p, idx, ti, tj);
+  if (p.kmode == 2) ti = p.mt - 1 - ti;
+  const int i0 = ti * TILE, j0 = tj * TILE;
+  int kbeg = 0, kend = p.k;
+  if (p.kmode == 1) kbeg = j0;
+  else if (p.kmode == 2) kend = i0 + TILE;
+  else if (p.kmode == 3) kbeg = i0;
+  else if (p.kmode == 4) kend = j0 + TILE;
+
+  const double* A = p.A + (long)blockIdx.z * p.strideA;
+  const double* B = p.B + (long)blockIdx.z * p.strideB;
+  double* C = p.C + (long)blockIdx.z * p.strideC;
+
+  double4_t acc[4][2];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+  const int nchunk = (kend - kbeg) / BKC;
+  unsigned gA, lA, gB, lB;
+  long sA, sB;
+  vc::chunk_offsets<A_KMAJOR>(p.lda, tid, gA, lA, sA);
+  vc::chunk_offsets<B_KMAJOR>(p.ldb, tid, gB, lB, sB);
+  const char* Ag = reinterpret_cast<const char*>(A_KMAJOR ? A + (long)kbeg * p.lda + i0 : A + (long)i0 * p.lda + kbeg);
+  const char* Bg = reinterpret_cast<const char*>(B_KMAJOR ? B + (long)kbeg * p.ldb + j0 : B + (long)j0 * p.ldb + kbeg);
+  const long stepA = (A_KMAJOR ? (long)BKC * p.lda : (long)BKC) * 8;
+  const long stepB = (B_KMAJOR ? (long)BKC * p.ldb : (long)BKC) * 8;
+  char* Asb = reinterpret_cast<char*>(As);
+  char* Bsb = reinterpret_cast<char*>(Bs);
+  double2_t ra[2][NQC], rb[2][NQC];  // global -> register prefetch two chunks ahead (see variant B)
+  if (nchunk > 0) {
+    vc::chunk_load(Ag, gA, sA, ra[0]);
+    vc::chunk_load(Bg, gB, sB, rb[0]);
+    if (nchunk > 1) {
+      Ag += stepA;
+      Bg += stepB;
+      vc::chunk_load(Ag, gA, sA, ra[1]);
+      vc::chunk_load(Bg, gB, sB, rb[1]);
+    }
+    vc::chunk_store<A_KMAJOR>(Asb, lA, ra[0]);
+    vc::chunk_store<B_KMAJOR>(Bsb, lB, rb[0]);
+  }
+  __syncthreads();
+
+  const int kq = lane >> 4, l15 = lane & 15;
+  const double* a_ptr = As + kq * LDS_LD + wr * 64 + l15;
+  const double* b_ptr = Bs + kq * LDS_LD + wc * 32 + l15;
+  double af[2][4], bf[2][2];
+  auto load_frags = [&](int set, int boff, int kk) {
+    const double* ap = a_ptr + boff + kk * 4 * LDS_LD;
+    const double* bp = b_ptr + boff + kk * 4 * LDS_LD;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) af[set][a] = ap[16 * a];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) bf[set][b] = bp[16 * b];
+  };
+  if (nchunk > 0) load_frags(0, 0, 0);
+
+  auto chunk_body = [&](int c, auto S) {
+    constexpr int s = decltype(S)::value;
+    constexpr int boff = s * OPER_C;
+    const bool adv = (c + 2 < nchunk);
+    Ag += adv ? stepA : 0;
+    Bg += adv ? stepB : 0;
+#pragma unroll
+    for (int kk = 0; kk < BKC / 4; ++kk) {
+      const int cur = kk & 1;
+      __builtin_amdgcn_sched_barrier(0);
+      if (kk == 0) {
+        vc::chunk_load(Ag, gA, sA, ra[s]);
+        vc::chunk_load(Bg, gB, sB, rb[s]);
+      }
+      if (kk + 1 < BKC / 4) load_frags(cur ^ 1, boff, kk + 1);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur][a], bf[cur][b], acc[a][b], 0, 0, 0);
+      if (kk == BKC / 4 - 1) {
+        constexpr int noff = (boff ^ OPER_C) * 8;
+        vc::chunk_store<A_KMAJOR>(Asb + noff, lA, ra[s ^ 1]);
+        vc::chunk_store<B_KMAJOR>(Bsb + noff, lB, rb[s ^ 1]);
+      }
+      if (kk == 0) {  // 8 MFMAs, 4 global loads, 3 ds_read2
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      } else if (kk + 1 < BKC / 4) {  // 8 MFMAs, 3 ds_read2
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      } else {  // 8 MFMAs and the LDS writes of the next chunk
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    load_frags(0, boff ^ OPER_C, 0);
+  };
+  for (int c = 0; c < nchunk; c += 2) {  // k is a multiple of 128, so nchunk is even
+    chunk_body(c, std::integral_constant<int, 0>());
+    chunk_body(c + 1, std::integral_constant<int, 1>());
+  }
+
+  const double alpha = p.alpha, beta = p.beta;
+  double* cbase = C + (long)(i0 + wr * 64 + kq) * p.ldc + j0 + wc * 32 + l15;
+  if (beta != 0.0) {
+    double4_t cv[2][2];
+    auto load_group = [&](int set, int a) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cv[set][b][r] = cbase[(long)(16 * a + 4 * r) * p.ldc + 16 * b];
+    };
+    load_group(0, 0);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      if (a + 1 < 4) load_group((a + 1) & 1, a + 1);
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          cbase[(long)(16 * a + 4 * r) * p.ldc + 16 * b] = alpha * acc[a][b][r] + beta * cv[a & 1][b][r];
+    }
+  } else {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cbase[(long)(16 * a + 4 * r) * p.ldc + 16 * b] = alpha * acc[a][b][r];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Variant S: 64x64 output tile per 256-thread workgroup (4 waves as 2x2, 32x32 per wave) for launches
 // with too few 128x128 tiles to fill the chip (the in-panel updates of the Cholesky, a few dozen to a
 // few hundred tiles, which sit on the factorisation's critical path): 4x the workgroups, 1/4 of the
@@ -575,38 +796,65 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel_s(GemmParams p) {
 
   const double* a_ptr = As + kq * LDS_S + wr * 32 + l15;
   const double* b_ptr = Bs + kq * LDS_S + wc * 32 + l15;
+  // Same schedule as variant B at a quarter of the tile: branch-free chunk body, operand fragments double-buffered
+  // one k4-step ahead, and the chunk's 4 global loads / 8 fragment reads / LDS writes spread between its 16 MFMAs.
+  double fa[2][2], fb[2][2];
+  auto load_frags = [&](int set, int boff, int kk) {
+    const double* ap = a_ptr + boff + kk * 4 * LDS_S;
+    const double* bp = b_ptr + boff + kk * 4 * LDS_S;
+    fa[set][0] = ap[0]; fa[set][1] = ap[16]; fb[set][0] = bp[0]; fb[set][1] = bp[16];
+  };
+  if (nchunk > 0) load_frags(0, 0, 0);
   for (int c = 0; c < nchunk; ++c) {
     const int boff = (c & 1) * OPER_S;
-    const bool more = (c + 1 < nchunk);
-    if (more) {
-      Ag += stepA;
-      Bg += stepB;
-      vs::chunk_load(Ag, gA, sA, ra);
-      vs::chunk_load(Bg, gB, sB, rb);
-    }
-    // all 16 fragment reads of the chunk first, then its 16 MFMAs: one exposed LDS latency per chunk, not four
-    double fa[BKS / 4][2], fb[BKS / 4][2];
+    const bool adv = (c + 1 < nchunk);
+    Ag += adv ? stepA : 0;
+    Bg += adv ? stepB : 0;
 #pragma unroll
     for (int kk = 0; kk < BKS / 4; ++kk) {
-      const double* ap = a_ptr + boff + kk * 4 * LDS_S;
-      const double* bp = b_ptr + boff + kk * 4 * LDS_S;
-      fa[kk][0] = ap[0]; fa[kk][1] = ap[16]; fb[kk][0] = bp[0]; fb[kk][1] = bp[16];
-    }
-    __builtin_amdgcn_sched_barrier(0);
+      const int cur = kk & 1;
+      __builtin_amdgcn_sched_barrier(0);
+      if (kk == 0) {
+        vs::chunk_load(Ag, gA, sA, ra);
+        vs::chunk_load(Bg, gB, sB, rb);
+      }
+      if (kk + 1 < BKS / 4) load_frags(cur ^ 1, boff, kk + 1);
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[cur][0], fb[cur][0], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[cur][0], fb[cur][1], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[cur][1], fb[cur][0], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[cur][1], fb[cur][1], acc[1][1], 0, 0, 0);
+      if (kk == BKS / 4 - 1) {
+        const int noff = (boff ^ OPER_S) * 8;
+        vs::chunk_store<A_KMAJOR>(Asb + noff, lA, ra);
+        vs::chunk_store<B_KMAJOR>(Bsb + noff, lB, rb);
+      }
+      if (kk == 0) {
 #pragma unroll
-    for (int kk = 0; kk < BKS / 4; ++kk) {
-      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[kk][0], fb[kk][0], acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[kk][0], fb[kk][1], acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[kk][1], fb[kk][0], acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[kk][1], fb[kk][1], acc[1][1], 0, 0, 0);
+        for (int g = 0; g < 2; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+      } else if (kk + 1 < BKS / 4) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+        }
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (more) {
-      const int noff = (boff ^ OPER_S) * 8;
-      vs::chunk_store<A_KMAJOR>(Asb + noff, lA, ra);
-      vs::chunk_store<B_KMAJOR>(Bsb + noff, lB, rb);
-    }
     __syncthreads();
+    load_frags(0, boff ^ OPER_S, 0);
   }
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -659,6 +907,16 @@ hipError_t launch_gemm_f64(const GemmParams& p, int opA_kmajor, int opB_kmajor, 
     else gemm_f64_kernel_s<true, false><<<grid, block, 0, stream>>>(q);
     return hipGetLastError();
   }
+  static const bool force_wide = getenv("MIGP_GEMM_WIDE") != nullptr;  // dev harnesses only
+  if (gemm_variant() == 1 && (p.wide8 || force_wide)) {
+    dim3 grid(nblk, 1, batch), block(vc::NT_C);
+    const size_t lds = sizeof(double) * 4 * vc::OPER_C;
+    if (!opA_kmajor && !opB_kmajor) gemm_f64_kernel_c<false, false><<<grid, block, lds, stream>>>(p);
+    else if (!opA_kmajor && opB_kmajor) gemm_f64_kernel_c<false, true><<<grid, block, lds, stream>>>(p);
+    else if (opA_kmajor && opB_kmajor) gemm_f64_kernel_c<true, true><<<grid, block, lds, stream>>>(p);
+    else gemm_f64_kernel_c<true, false><<<grid, block, lds, stream>>>(p);
+    return hipGetLastError();
+  }
   if (gemm_variant() == 1) {
     dim3 grid(nblk, 1, batch), block(vb::NT_B);
     const size_t lds = p.one_per_cu ? LDS_ONE_PER_CU : sizeof(double) * 4 * vb::OPER_B;
@@ -688,6 +946,17 @@ hipError_t gemm_f64_enable_lds() {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+  }
+  {
+    const int ldsc = (int)(sizeof(double) * 4 * vc::OPER_C);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_kernel_c<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsc);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_kernel_c<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsc);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_kernel_c<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsc);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_kernel_c<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsc);
     if (e != hipSuccess) return e;
   }
   const int ldsb = (int)LDS_ONE_PER_CU;

@@ -1,4 +1,4 @@
-"""A/B: in-panel updates inside the next leaf's launch (option 9) with graph on/off; checks bit-identical LML."""
+"""A/B: look-ahead bulk updates on the 8-wave one-workgroup-per-CU GEMM (option 9) with graph on/off."""
 import sys, time, os
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -21,5 +21,5 @@ for N in (1000, 4096, 8192, 16384):
                 for _ in range(5): gp.lml(theta)
                 res.setdefault((graph, split), []).append((time.perf_counter() - t0) / 5 * 1e3)
     g0 = gp.lml_grad(theta)
-    print(N, {k: round(min(v), 3) for k, v in res.items()}, "bit-identical:", len(set(vals.values())) == 1, flush=True)
+    print(N, {k: round(min(v), 3) for k, v in res.items()}, "max rel diff:", max(abs(v - vals[(0, 0)]) / abs(vals[(0, 0)]) for v in vals.values()), flush=True)
     gp.close()

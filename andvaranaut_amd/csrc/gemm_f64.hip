@@ -118,6 +118,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(GemmParams p) {
   int ti, tj;
   tile_from_index(p, idx, ti, tj);
   if (p.kmode == 2) ti = p.mt - 1 - ti;  // longest-K tiles (largest ti) first
+  if (p.kmode == 4 && !p.tri) { tj = p.nt - 1 - idx / p.mt; ti = idx % p.mt; }  // k < (tj+1)*128: longest-k COLUMNS first
   const int i0 = ti * TILE, j0 = tj * TILE;
   int kbeg = 0, kend = p.k;
   if (p.kmode == 1) kbeg = j0;
@@ -304,6 +305,7 @@ __global__ __launch_bounds__(vb::NT_B, 2) void gemm_f64_kernel_b(GemmParams p) {
   int ti, tj;
   tile_from_index(p, idx, ti, tj);
   if (p.kmode == 2) ti = p.mt - 1 - ti;
+  if (p.kmode == 4 && !p.tri) { tj = p.nt - 1 - idx / p.mt; ti = idx % p.mt; }  // longest-k columns first (LPT order)
   const int i0 = ti * TILE, j0 = tj * TILE;
   int kbeg = 0, kend = p.k;
   if (p.kmode == 1) kbeg = j0;
@@ -532,6 +534,7 @@ __global__ __launch_bounds__(vc::NT_C, 1) void gemm_f64_kernel_c(GemmParams p) {
   int ti, tj;
   tile_from_index(p, idx, ti, tj);
   if (p.kmode == 2) ti = p.mt - 1 - ti;
+  if (p.kmode == 4 && !p.tri) { tj = p.nt - 1 - idx / p.mt; ti = idx % p.mt; }  // longest-k columns first (LPT order)
   const int i0 = ti * TILE, j0 = tj * TILE;
   int kbeg = 0, kend = p.k;
   if (p.kmode == 1) kbeg = j0;
@@ -743,6 +746,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel_s(GemmParams p) {
   int ti, tj;
   tile_from_index(p, blockIdx.x, ti, tj);
   if (p.kmode == 2) ti = p.mt - 1 - ti;
+  if (p.kmode == 4 && !p.tri) { tj = p.nt - 1 - (int)blockIdx.x / p.mt; ti = (int)blockIdx.x % p.mt; }  // longest-k columns first (LPT order)
   const int i0 = ti * TS, j0 = tj * TS;
   int kbeg = 0, kend = p.k;
   if (p.kmode == 1) kbeg = j0;

@@ -22,6 +22,7 @@ struct mi_gp_handle {
   hipEvent_t ev_panel, ev_upd;
   int lookahead;
   int use_graph;
+  int bulk_wide_late, bulk_wide_thr;  // CU count of the persistent bulk kernel once <= thr tile columns remain
   int bulk_wide;   // look-ahead bulk updates on the 8-wave / one-workgroup-per-CU GEMM kernel (variant C)
   int lowocc_thr;  // trailing sizes (tile columns) at or below which bulk updates run one workgroup per CU
   int w_thr[3];  // trailing sizes (tile columns) above which the super-panel is 16 / 8 / 4 tiles wide
@@ -110,6 +111,8 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   h->lookahead = 1;
   h->use_graph = 1;
   h->bulk_wide = 0;
+  h->bulk_wide_late = 224;
+  h->bulk_wide_thr = 0;
   h->lowocc_thr = 64;
   h->w_thr[0] = 1 << 20; h->w_thr[1] = 72; h->w_thr[2] = 0;
   if (e == hipSuccess) e = hipMalloc(&h->theta_dev, sizeof(double) * h->ntheta);
@@ -181,7 +184,9 @@ extern "C" int mi_gp_set_option(mi_gp_handle* h, int what, int value) {
   else if (what >= 4 && what <= 6) h->w_thr[what - 4] = value;
   else if (what == 7) set_gemm_small_tiles(value);
   else if (what == 8) h->lowocc_thr = value;
-  else if (what == 9) h->bulk_wide = value ? 1 : 0;
+  else if (what == 9) h->bulk_wide = value;
+  else if (what == 10) h->bulk_wide_late = value;
+  else if (what == 11) h->bulk_wide_thr = value;
   else return -1;
   return 0;
 }
@@ -304,7 +309,7 @@ static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int nt
     // (b) runs next to the panel chain: the 8-wave kernel leaves half of every CU to it
     if (n1 + wn < ntc)
       CKE(syrk_trapezoid(h, A, lda, ntr, n1 + wn, ntc - n1 - wn, J, w, T,
-                         (P != T && !h->bulk_wide && ntc - n1 <= h->lowocc_thr) ? 1 : 0, (P != T && h->bulk_wide) ? 1 : 0));
+                         (P != T && !h->bulk_wide && ntc - n1 <= h->lowocc_thr) ? 1 : 0, (P != T) ? ((ntc - n1 <= h->bulk_wide_thr) ? h->bulk_wide_late : h->bulk_wide) : 0));
     J = n1;
     w = wn;
   }
@@ -354,8 +359,8 @@ static int run_evaluation(mi_gp_handle* h, int what) {
     if (what == 2) { if (int r = enqueue_gradient(h, prof)) return r; }
     return download_results(h, what);
   }
-  const int key = what | (h->lookahead << 4) | (h->bulk_wide << 5) | ((h->cfg.panel_tiles & 0xff) << 8) | (gemm_variant_get() << 20) |
-                  ((h->w_thr[0] * 31 + h->w_thr[1] * 7 + h->w_thr[2] + h->lowocc_thr * 13) & 0x7ff) << 21;
+  const int key = what | (h->lookahead << 4) | ((h->bulk_wide ? 1 : 0) << 5) | ((h->cfg.panel_tiles & 0xff) << 8) | (gemm_variant_get() << 20) |
+                  ((h->w_thr[0] * 31 + h->w_thr[1] * 7 + h->w_thr[2] + h->lowocc_thr * 13 + h->bulk_wide * 3 + h->bulk_wide_late * 5 + h->bulk_wide_thr * 11) & 0x7ff) << 21;
   auto it = h->graphs.find(key);
   if (it == h->graphs.end()) {
     // First use: time one evaluation with plain launches, then capture + instantiate and time a

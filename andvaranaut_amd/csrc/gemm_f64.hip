@@ -473,8 +473,13 @@ __global__ __launch_bounds__(vb::NT_B, 2) void gemm_f64_kernel_b(GemmParams p) {
 // it reaches 73.0 TFLOP/s on 8192^3 (B: 75.5) and 66.8 on the k=1024 trapezoid (B: 69.1).  As the look-ahead bulk
 // kernel it changes nothing (N=16384: 30.8 vs 30.7 ms): the chain's kernels do find a slot at once, but next to
 // MFMA-saturated waves they still run 1.7-2.2x slower than alone (leaf 75 us vs 34) -- it is execution
-// contention on the CU, not waiting for a free slot, that stretches the panel stream.  Kept as the building
-// block for a CU-partitioned (persistent) trailing update.
+// contention on the CU, not waiting for a free slot, that stretches the panel stream.
+// Persistent form (option 9 = n > 1): n workgroups, each asking for a whole CU's LDS, walk the tiles with stride n, which
+// pins the trailing update to n CUs and leaves 256 - n to the panel chain.  With n = 224 (28 per XCD) the leaf runs at
+// its stand-alone 33 us and the strip at 42 us next to it, but the in-panel GEMMs (24 % of all flops) are then confined to
+// 32 CUs and the trailing update loses 1/8 of the chip: 29.9 vs 30.5 ms with plain launches, no change under graph replay;
+// n = 232 or 192 are 2-3 ms worse, switching n by phase does not help (tools/dev_ab8.py).  Throughput work is conserved:
+// a static CU split only moves the bottleneck.  Kept as a building block for a tile-DAG scheduler.
 namespace vc {
 constexpr int BKC = 16;
 constexpr int OPER_C = BKC * LDS_LD;
@@ -525,9 +530,13 @@ __global__ __launch_bounds__(vc::NT_C, 1) void gemm_f64_kernel_c(GemmParams p) {
   const int wave = tid >> 6;
   const int wr = wave >> 2, wc = wave & 3;
 
+  // p.ntiles > gridDim.x: persistent form -- workgroup b handles tiles b, b + gridDim.x, ... (a grid smaller than the
+  // chip with a whole-CU LDS request pins the trailing update to that many CUs and leaves the others to the chain)
+  const int ntiles = p.ntiles > 0 ? p.ntiles : (int)gridDim.x;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
   const int nblk = gridDim.x;
-  int idx = blockIdx.x;
-  if (p.kmode == 0) {
+  int idx = tile;
+  if (p.kmode == 0 && ntiles == nblk) {
     const int b = blockIdx.x, x = b & 7, q = nblk >> 3, r = nblk & 7;
     idx = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
   }
@@ -684,6 +693,8 @@ __global__ __launch_bounds__(vc::NT_C, 1) void gemm_f64_kernel_c(GemmParams p) {
       for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int r = 0; r < 4; ++r) cbase[(long)(16 * a + 4 * r) * p.ldc + 16 * b] = alpha * acc[a][b][r];
+  }
+  __syncthreads();  // the next tile's prologue overwrites the LDS buffers
   }
 }
 
@@ -887,7 +898,8 @@ static int gemm_variant() {
 }
 
 static int g_small_tiles = 1024;
-constexpr size_t LDS_ONE_PER_CU = 84 * 1024;  // 160 KB per CU: two of these do not fit, one + a 76 KB leaf does
+constexpr size_t LDS_ONE_PER_CU = 84 * 1024;
+constexpr size_t LDS_WHOLE_CU = 160 * 1024;  // 160 KB per CU: two of these do not fit, one + a 76 KB leaf does
 void set_gemm_variant(int v) { g_variant = v; }
 void set_gemm_small_tiles(int v) { g_small_tiles = v; }
 static int tile_count(const GemmParams& p);
@@ -913,8 +925,16 @@ hipError_t launch_gemm_f64(const GemmParams& p, int opA_kmajor, int opB_kmajor, 
   }
   static const bool force_wide = getenv("MIGP_GEMM_WIDE") != nullptr;  // dev harnesses only
   if (gemm_variant() == 1 && (p.wide8 || force_wide)) {
-    dim3 grid(nblk, 1, batch), block(vc::NT_C);
-    const size_t lds = sizeof(double) * 4 * vc::OPER_C;
+    GemmParams pc = p;
+    int g = nblk;
+    size_t lds = sizeof(double) * 4 * vc::OPER_C;
+    if (p.wide8 > 1 && batch == 1 && nblk > p.wide8) {  // persistent on p.wide8 CUs, each taken whole
+      pc.ntiles = nblk;
+      g = p.wide8;
+      lds = LDS_WHOLE_CU;
+    }
+    const GemmParams& p = pc;
+    dim3 grid(g, 1, batch), block(vc::NT_C);
     if (!opA_kmajor && !opB_kmajor) gemm_f64_kernel_c<false, false><<<grid, block, lds, stream>>>(p);
     else if (!opA_kmajor && opB_kmajor) gemm_f64_kernel_c<false, true><<<grid, block, lds, stream>>>(p);
     else if (opA_kmajor && opB_kmajor) gemm_f64_kernel_c<true, true><<<grid, block, lds, stream>>>(p);
@@ -953,7 +973,7 @@ hipError_t gemm_f64_enable_lds() {
     if (e != hipSuccess) return e;
   }
   {
-    const int ldsc = (int)(sizeof(double) * 4 * vc::OPER_C);
+    const int ldsc = (int)LDS_WHOLE_CU;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_kernel_c<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsc);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_kernel_c<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsc);

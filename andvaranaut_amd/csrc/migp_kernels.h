@@ -17,7 +17,8 @@ struct GemmParams {
   int tri;                         // 1: only tiles with tj <= min(ti, nt-1)  (SYRK / trapezoid)
   int kmode;                       // 0 full k; 1 k >= tj*128; 2 k < (ti+1)*128; 3 k >= ti*128; 4 k < (tj+1)*128
   double alpha, beta;
-  int wide8 = 0;                    // launcher only: 8-wave / one-workgroup-per-CU kernel (variant C) that leaves half of
+  int ntiles = 0;                   // variant C persistent form: total tiles when the grid is smaller (set by the launcher)
+  int wide8 = 0;                    // launcher only: 1 = 8-wave / one-workgroup-per-CU kernel (variant C) that leaves half of
                                     // every CU's LDS and registers to the panel chain
   int one_per_cu = 0;               // launcher only: request > half a CU's LDS so that one workgroup per CU runs (leaves room for
                                     // the panel chain's leaf / strip kernels next to a bulk update)

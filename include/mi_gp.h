@@ -107,7 +107,12 @@ int mi_gp_predict_grad(mi_gp_handle* h, const double* Xnew_dev, int m, double* w
 /* tuning knobs (benchmarks / A-B tests): what = 0 one-super-panel look-ahead on the second stream
  * (per handle, default 1); 1 GEMM kernel variant (process-wide: 0 = 8 waves, 1 workgroup per CU;
  * 1 = 4 waves, 2 workgroups per CU, default); 2 super-panel width in 128-column tiles;
- * 3 replay each evaluation from a captured hipGraph (default 1; profiling levels >= 1 use plain launches). */
+ * 3 replay each evaluation from a captured hipGraph (default 1; profiling levels >= 1 use plain launches);
+ * 4-6 trailing sizes (tile columns) above which the super-panel is 16 / 8 / 4 tiles wide (below the last: 2);
+ * 7 launches with fewer 128x128 tiles than this run on 64x64 tiles (process-wide, default 1024; not part of the
+ * graph key: use with option 3 = 0); 8 trailing size at or below which look-ahead bulk updates run one workgroup
+ * per CU (default 64); 9 look-ahead bulk kernel: 0 = 4-wave kernel (default), 1 = 8-wave / one workgroup per CU,
+ * n > 1 = the same persistent on n CUs taken whole; 10, 11 = CU count used once <= (11) tile columns remain. */
 int mi_gp_set_option(mi_gp_handle* h, int what, int value);
 
 /* profiling: level 0 none, 1 per-phase HIP events, 2 additionally per-GEMM-launch HIP events */

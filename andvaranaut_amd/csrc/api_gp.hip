@@ -35,6 +35,7 @@ struct mi_gp_handle {
   double* dinv_dev;     // [ntc][8][16][16]
   double* alpha_dev;    // [np] K^-1 y
   double* part_dev;     // [grad_contract_blocks(n)][ntheta]
+  double* gxs_dev;      // [grad_x_splits][n][d] partial dLML/dX (allocated on first mi_gp_grad_x)
   double* grad_dev;     // [ntheta]
   double* grad_host;    // pinned [ntheta]
   int* info_dev;
@@ -95,6 +96,7 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   h->have_kinv = false;
   h->have_u = false;
   h->diag_dev = nullptr;
+  h->gxs_dev = nullptr;
   h->t_trtri_ms = h->t_lauum_ms = h->t_contract_ms = 0.0;
   h->t_gemm_big_ms = h->gemm_big_flops = h->n_gemm_big = 0.0;
   h->prof_level = 0;
@@ -144,7 +146,7 @@ extern "C" int mi_gp_destroy(mi_gp_handle* h) {
   hipSetDevice(h->device);
   hipStreamSynchronize(h->stream);
   hipFree(h->theta_dev); hipFree(h->out_dev); hipFree(h->dinv_dev); hipFree(h->info_dev);
-  hipFree(h->alpha_dev); hipFree(h->part_dev); hipFree(h->grad_dev); hipHostFree(h->grad_host);
+  hipFree(h->alpha_dev); hipFree(h->part_dev); if (h->gxs_dev) hipFree(h->gxs_dev); hipFree(h->grad_dev); hipHostFree(h->grad_host);
   hipHostFree(h->out_host); hipHostFree(h->info_host); hipHostFree(h->theta_host);
   for (int i = 0; i < 8; ++i) hipEventDestroy(h->ev[i]);
   for (auto& ev : h->gemm_ev) hipEventDestroy(ev);
@@ -182,7 +184,11 @@ extern "C" int mi_gp_set_option(mi_gp_handle* h, int what, int value) {
   else if (what == 2) h->cfg.panel_tiles = value;
   else if (what == 3) h->use_graph = value ? 1 : 0;
   else if (what >= 4 && what <= 6) h->w_thr[what - 4] = value;
-  else if (what == 7) set_gemm_small_tiles(value);
+  else if (what == 7) {
+    set_gemm_small_tiles(value);
+    for (auto& kv : h->graphs) if (kv.second) hipGraphExecDestroy(kv.second);  // captured launches used the old routing
+    h->graphs.clear();
+  }
   else if (what == 8) h->lowocc_thr = value;
   else if (what == 9) h->bulk_wide = value;
   else if (what == 10) h->bulk_wide_late = value;
@@ -582,8 +588,11 @@ extern "C" int mi_gp_grad_x(mi_gp_handle* h, double* gx_dev) {
   if (!h->have_kinv) { snprintf(h->err, sizeof(h->err), "mi_gp_grad_x: call mi_gp_lml_grad first"); return -1; }
   if (h->cfg.d > 128) { snprintf(h->err, sizeof(h->err), "mi_gp_grad_x: d <= 128"); return -1; }
   HCK(hipSetDevice(h->device), "hipSetDevice");
-  HCK(launch_grad_x(h->spec, h->theta_dev, h->buf.X_dev, h->n, h->buf.W_dev, h->buf.lda, h->alpha_dev, gx_dev, h->stream),
-      "grad_x");
+  const int nsplit = grad_x_splits(h->n, h->cfg.d);
+  if (nsplit > 1 && !h->gxs_dev)
+    HCK(hipMalloc(&h->gxs_dev, sizeof(double) * (size_t)nsplit * h->n * h->cfg.d), "grad_x scratch");
+  HCK(launch_grad_x(h->spec, h->theta_dev, h->buf.X_dev, h->n, h->buf.W_dev, h->buf.lda, h->alpha_dev, gx_dev,
+                    nsplit > 1 ? h->gxs_dev : nullptr, h->stream), "grad_x");
   HCK(hipStreamSynchronize(h->stream), "stream sync");
   return 0;
 }
@@ -662,13 +671,35 @@ extern "C" int mi_gp_predict_grad(mi_gp_handle* h, const double* Xnew_dev, int m
     return -1;
   }
   if (h->cfg.d > 128) { snprintf(h->err, sizeof(h->err), "mi_gp_predict_grad: d <= 128"); return -1; }
-  const int r = mi_gp_predict(h, Xnew_dev, m, work_dev, ldw, mean_dev, var_dev, pred_noise);
-  if (r != 0) return r;
+  if (!h->factored) { snprintf(h->err, sizeof(h->err), "mi_gp_predict_grad: call mi_gp_factor first"); return -1; }
+  if (!Xnew_dev || !work_dev || !mean_dev || !var_dev || m <= 0) return -1;
+  if (ldw < h->np || (ldw & 1)) { snprintf(h->err, sizeof(h->err), "mi_gp_predict_grad: ldw must be even and >= padded n"); return -1; }
+  HCK(hipSetDevice(h->device), "hipSetDevice");
   const long ld = h->buf.lda;
   if (!h->have_u) {
     HCK(inverse_transpose(h), "inverse_transpose");
     HCK(launch_trmv_upper(h->buf.Z_dev, ld, h->buf.K_dev + (long)h->np * ld, h->n, h->alpha_dev, h->stream), "trmv");
     h->have_u = true;
+  }
+  if (m <= 16) {
+    // few points (BO refinement): with U resident, A_p = L^-1 k*_p = U^T k*_p is one pass over U per point instead
+    // of the ~250-launch blocked triangular solve
+    const int mp = (m + 127) / 128 * 128;
+    double* krows = work_dev + (long)mp * ldw;  // K(X*, X) rows; overwritten by the w rows below
+    HCK(launch_assemble(h->spec, h->theta_dev, Xnew_dev, m, h->buf.X_dev, h->n, krows, ldw, mp, h->np, 0, 0, h->stream),
+        "assemble cross");
+    for (int p = 0; p < m; ++p)
+      HCK(launch_trmv_upper_t(h->buf.Z_dev, ld, krows + (long)p * ldw, h->n, work_dev + (long)p * ldw, h->stream), "trmv_t");
+    const int nk = h->spec.nkern, d = h->spec.d;
+    const double* th = h->theta_host;
+    double kd = th[nk * d];
+    for (int c = 1; c < nk; ++c) kd = (h->spec.op[c - 1] == 0) ? kd + th[nk * d + c] : kd * th[nk * d + c];
+    const double sg = std::sqrt(th[nk * d + 2 * nk]);
+    HCK(launch_predict_reduce(work_dev, ldw, h->buf.K_dev + (long)h->np * h->buf.lda, h->n, m, kd,
+                              pred_noise ? sg * sg : 0.0, mean_dev, var_dev, h->stream), "predict_reduce");
+  } else {
+    const int r = mi_gp_predict(h, Xnew_dev, m, work_dev, ldw, mean_dev, var_dev, pred_noise);
+    if (r != 0) return r;
   }
   const int mp = (m + 127) / 128 * 128;
   double* wrows = work_dev + (long)mp * ldw;

@@ -42,6 +42,38 @@ __global__ __launch_bounds__(256) void trmv_upper_kernel(const double* __restric
   if (lane == 0) alpha[row] = s;
 }
 
+// out[i] = sum_{k <= i} U[k][i] * x[k]  (U^T x = L^-1 x for U = L^-T), columns [0, n).  One workgroup per 64 columns;
+// wave g walks rows k = g (mod 4), 8 independent loads in flight per lane: consecutive lanes read consecutive doubles of
+// one row of U (512 B per wave load), x[k] is a broadcast; the four partial sums meet in LDS in a fixed order.
+__global__ __launch_bounds__(256) void trmv_upper_t_kernel(const double* __restrict__ U, long ld,
+                                                           const double* __restrict__ x, int n,
+                                                           double* __restrict__ out) {
+  __shared__ double part[4][64];
+  const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + c;
+  const int kmax = min(n - 1, blockIdx.x * 64 + 63);
+  const bool live = i < n;
+  double s[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) s[u] = 0.0;
+  int k = g;
+  for (; k + 28 <= kmax; k += 32) {
+    double uv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int kk = k + 4 * u;
+      uv[u] = (live && kk <= i) ? U[(long)kk * ld + i] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s[u] += uv[u] * x[k + 4 * u];
+  }
+  for (; k <= kmax; k += 4)
+    if (live && k <= i) s[0] += U[(long)k * ld + i] * x[k];
+  part[g][c] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+  __syncthreads();
+  if (g == 0 && live) out[i] = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+}
+
 // d k / d r2 of the base kernels (matches oracle base_kernel_dr2) and the value itself
 __device__ __forceinline__ void base_kernel_val_der(int kid, double r2, double alpha, double& k, double& dk,
                                                     double& dalpha) {
@@ -289,6 +321,8 @@ __global__ __launch_bounds__(256) void grad_x_kernel(KernSpec spec, const double
                                                      const double* __restrict__ X, int n,
                                                      const double* __restrict__ W, long ldw,
                                                      const double* __restrict__ alpha_v, double* __restrict__ gx) {
+  // gridDim.y > 1: this workgroup walks column blocks blockIdx.y, blockIdx.y + gridDim.y, ... and writes its partial
+  // result to slab blockIdx.y of gx ([gridDim.y][n][d]); gx_reduce_kernel adds the slabs in order
   __shared__ double Xi[GT * GXLD];
   __shared__ double Xj[GT * GXLD];
   __shared__ double Ct[GT * (GT + 1)];
@@ -308,7 +342,8 @@ __global__ __launch_bounds__(256) void grad_x_kernel(KernSpec spec, const double
 #pragma unroll
     for (int u = 0; u < GXCH / 4; ++u) acc[mc][u] = 0.0;
 
-  for (int jb = 0; jb < nt; ++jb) {
+  gx += (long)blockIdx.y * n * d;
+  for (int jb = blockIdx.y; jb < nt; jb += gridDim.y) {
     const int j0 = jb * GT;
     __syncthreads();  // previous block's pass 2 is done with Ct / Xj
     // symmetric weight tile, coalesced along whichever index is contiguous in the stored lower triangle
@@ -632,10 +667,35 @@ hipError_t launch_predict_grad(const KernSpec& spec, const double* theta, const 
   return hipGetLastError();
 }
 
+hipError_t launch_trmv_upper_t(const double* U, long ld, const double* x, int n, double* out, hipStream_t stream) {
+  trmv_upper_t_kernel<<<(n + 63) / 64, 256, 0, stream>>>(U, ld, x, n, out);
+  return hipGetLastError();
+}
+
+__global__ void gx_reduce_kernel(const double* __restrict__ part, int nsplit, long len, double* __restrict__ gx) {
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < len; e += (long)gridDim.x * blockDim.x) {
+    double s = part[e];
+    for (int k = 1; k < nsplit; ++k) s += part[(long)k * len + e];
+    gx[e] = s;
+  }
+}
+
+int grad_x_splits(int n, int d) {
+  const int nrb = (n + GT - 1) / GT;
+  int s = (512 + nrb - 1) / nrb;
+  if (s > 8) s = 8;
+  if (s > nrb) s = nrb;
+  while (s > 1 && (size_t)s * n * d * sizeof(double) > ((size_t)256 << 20)) --s;
+  return s < 1 ? 1 : s;
+}
+
+// scratch: [grad_x_splits(n, d)][n][d] doubles when more than one split is used (may be null otherwise)
 hipError_t launch_grad_x(const KernSpec& spec, const double* theta, const double* X, int n, const double* W, long ldw,
-                         const double* alpha, double* gx, hipStream_t stream) {
+                         const double* alpha, double* gx_out, double* scratch, hipStream_t stream) {
   if (spec.d > GX_MAXD) return hipErrorInvalidValue;
-  const int nblk = (n + GT - 1) / GT;
+  const int nsplit = scratch ? grad_x_splits(n, spec.d) : 1;
+  double* gx = nsplit > 1 ? scratch : gx_out;
+  const dim3 nblk((n + GT - 1) / GT, nsplit);
 #define GX_LAUNCH(NK_)                                                                                    \
   do {                                                                                                   \
     if (spec.d <= GXCH) grad_x_kernel<NK_, 1><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, gx);          \
@@ -649,6 +709,10 @@ hipError_t launch_grad_x(const KernSpec& spec, const double* theta, const double
     default: GX_LAUNCH(4); break;
   }
 #undef GX_LAUNCH
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess || nsplit == 1) return e;
+  const long len = (long)n * spec.d;
+  gx_reduce_kernel<<<(int)((len + 255) / 256 < 1024 ? (len + 255) / 256 : 1024), 256, 0, stream>>>(scratch, nsplit, len, gx_out);
   return hipGetLastError();
 }
 

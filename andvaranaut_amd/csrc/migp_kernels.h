@@ -66,13 +66,16 @@ hipError_t launch_lml_reduce(const double* L, long ld, const double* beta, int n
 // ---------------------------------------------------------------- grad_predict.hip
 hipError_t launch_set_identity_blocks(double* U, long ld, int nblocks, hipStream_t stream);
 hipError_t launch_trmv_upper(const double* U, long ld, const double* beta, int n, double* alpha, hipStream_t stream);
+// out = U^T x (= L^-1 x for U = L^-T)
+hipError_t launch_trmv_upper_t(const double* U, long ld, const double* x, int n, double* out, hipStream_t stream);
 int grad_contract_blocks(int n);
 // part: [grad_contract_blocks(n)][ntheta] scratch; grad: [ntheta] (natural parameters, C-ABI order)
 hipError_t launch_grad_contract(const KernSpec& spec, const double* theta, const double* X, int n, const double* W,
                                 long ldw, const double* alpha, double* part, double* grad, hipStream_t stream);
 // gx: [n][d] dLML/dX from Kinv (lower triangle in W) and alpha; d <= 128
+int grad_x_splits(int n, int d);  // column splits; scratch of [splits][n][d] doubles is needed when > 1
 hipError_t launch_grad_x(const KernSpec& spec, const double* theta, const double* X, int n, const double* W, long ldw,
-                         const double* alpha, double* gx, hipStream_t stream);
+                         const double* alpha, double* gx, double* scratch, hipStream_t stream);
 // dmean/dvar: [m][d] gradients of the conditional at m points; w: row p = K^-1 k(X, x*_p) (leading dimension ldw)
 hipError_t launch_predict_grad(const KernSpec& spec, const double* theta, const double* X, int n, const double* xstar,
                                int m, const double* alpha, const double* w, long ldw, double* dmean, double* dvar,

@@ -49,8 +49,8 @@ typedef struct mi_gp_buffers {
   double* K_dev;       /* (np+128) x lda, np = mi_gp_padded_n(): covariance, overwritten by its
                           lower Cholesky factor; the extra 128 rows carry y^T -> beta^T = (L^-1 y)^T */
   long lda;            /* leading dimension of K/Z/W in elements: even, >= np */
-  double* Z_dev;       /* np x lda  L^-1   (needed by mi_gp_lml_grad only; may be NULL otherwise) */
-  double* W_dev;       /* np x lda  K^-1   (needed by mi_gp_lml_grad only; may be NULL otherwise) */
+  double* Z_dev;       /* np x lda  U = L^-T, upper triangular (mi_gp_lml_grad / mi_gp_predict_grad only; else may be NULL) */
+  double* W_dev;       /* np x lda  K^-1 (lower triangle) and GEMM scratch (same entry points; else may be NULL) */
 } mi_gp_buffers;
 
 const char* mi_gp_last_global_error(void);
@@ -109,8 +109,7 @@ int mi_gp_predict_grad(mi_gp_handle* h, const double* Xnew_dev, int m, double* w
  * 1 = 4 waves, 2 workgroups per CU, default); 2 super-panel width in 128-column tiles;
  * 3 replay each evaluation from a captured hipGraph (default 1; profiling levels >= 1 use plain launches);
  * 4-6 trailing sizes (tile columns) above which the super-panel is 16 / 8 / 4 tiles wide (below the last: 2);
- * 7 launches with fewer 128x128 tiles than this run on 64x64 tiles (process-wide, default 1024; not part of the
- * graph key: use with option 3 = 0); 8 trailing size at or below which look-ahead bulk updates run one workgroup
+ * 7 launches with fewer 128x128 tiles than this run on 64x64 tiles (process-wide, default 1024); 8 trailing size at or below which look-ahead bulk updates run one workgroup
  * per CU (default 64); 9 look-ahead bulk kernel: 0 = 4-wave kernel (default), 1 = 8-wave / one workgroup per CU,
  * n > 1 = the same persistent on n CUs taken whole; 10, 11 = CU count used once <= (11) tile columns remain. */
 int mi_gp_set_option(mi_gp_handle* h, int what, int value);

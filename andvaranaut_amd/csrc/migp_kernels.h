@@ -34,6 +34,7 @@ bool gemm_uses_small_tiles(const GemmParams& p, int batch);  // true: the 64x64-
 
 // ---------------------------------------------------------------- leaf_f64.hip
 hipError_t leaf_enable_lds();
+void set_leaf_exclusive(int on);
 // in-place lower Cholesky of one 128x128 diagonal block; dinv receives the inverses of its eight
 // 16x16 diagonal sub-blocks ([8][16][16]); *info gets atomicMin(col0 + j + 1) on a bad pivot.
 hipError_t launch_potrf_leaf128(double* Ablk, long lda, double* dinv, int col0, int* info, hipStream_t stream);

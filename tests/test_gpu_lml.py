@@ -189,3 +189,24 @@ def test_tuning_options_do_not_change_results():
     for what, value in [(0, 1), (1, 1), (2, 0), (3, 1), (7, 1024)]:  # back to the defaults (1 and 7 are process-wide)
         gp.set_option(what, value)
     gp.close()
+
+
+def test_alternative_bulk_kernels_and_exclusive_leaf_are_bit_identical():
+    """The optional look-ahead bulk kernels (8-wave variant C, its persistent forms on a CU subset) and the
+    whole-CU leaf only change scheduling: every tile is still accumulated in the same order."""
+    MiGP, orc = _mods()
+    X, y = orc.synth_problem(5000, 5, seed=4)
+    theta = orc.synth_theta(5)
+    gp = MiGP(X, y, "RBF", need_grad=False)
+    gp.set_option(3, 0)
+    ref = gp.lml(theta)
+    assert abs(ref - orc.lml(X, y, ["RBF"], [], theta)) <= 1e-10 * abs(ref)
+    for opts in ([(9, 1)], [(9, 224)], [(9, 0x1000 | 248), (12, 1)], [(9, 0), (10, 1), (11, 1 << 20)], [(8, 1 << 20)]):
+        for what, value in opts:
+            gp.set_option(what, value)
+        for graph in (0, 1):
+            gp.set_option(3, graph)
+            assert gp.lml(theta) == ref and gp.lml(theta) == ref, (opts, graph)
+        for what, value in [(9, 0), (10, 0), (11, 0), (12, 0), (8, 64), (3, 0)]:
+            gp.set_option(what, value)
+    gp.close()

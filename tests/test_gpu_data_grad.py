@@ -157,3 +157,28 @@ def test_predictive_gradients_match_oracle(N, d, kernel, M):
     _, _, dmu3, _ = gp.predict_grad(theta, Xn)
     assert np.allclose(dmu3, dmu, rtol=1e-12, atol=0)
     gp.close()
+
+
+def test_device_data_gradients_match_mpmath_golden():
+    """The device entry points against the 50-digit mpmath vectors directly (tests/golden/mpmath_data_grad.json)."""
+    import json
+    import os
+
+    MiGP, _ = _mods()
+    with open(os.path.join(os.path.dirname(__file__), "golden", "mpmath_data_grad.json")) as f:
+        cases = json.load(f)
+    for c in cases:
+        X, y, xs = np.array(c["X"]), np.array(c["y"]), np.array([c["xstar"]])
+        theta = np.concatenate([np.array(c["ls"]).ravel(), c["kv"], c["alpha"], [c["gv"], c["jitter"]]])
+        kernel = c["kerns"][0]
+        for o, k in zip(c["ops"], c["kerns"][1:]):
+            kernel += o + k
+        gp = MiGP(X, y, kernel)
+        _, _, gy, gX = gp.lml_grad_data(theta)
+        _, _, dmu, dvar = gp.predict_grad(theta, xs, pred_noise=False)
+        tol = 1e-6 if "Exponential" in c["kerns"] else 1e-8
+        for got, key in ((gX, "gX"), (gy, "gy"), (dmu[0], "dmu"), (dvar[0], "dvar")):
+            ref = np.array(c[key], dtype=object)
+            ref = np.array([[float(v) for v in row] for row in ref]) if key == "gX" else np.array([float(v) for v in ref])
+            assert np.abs(got - ref).max() <= tol * max(np.abs(ref).max(), 1e-300), (c["name"], key)
+        gp.close()

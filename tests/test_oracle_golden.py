@@ -119,3 +119,37 @@ def test_non_pd_gives_minus_inf():
     y = np.ones(4)
     theta = orc.pack_theta([[1.0]], [1.0], 0.0, -1e-3)
     assert orc.lml(X, y, ["RBF"], [], theta) == -np.inf
+
+
+def _data_grad_cases():
+    import json
+    import os
+
+    with open(os.path.join(os.path.dirname(__file__), "golden", "mpmath_data_grad.json")) as f:
+        return json.load(f)
+
+
+def _case_arrays(c):
+    X, y, xs = np.array(c["X"]), np.array(c["y"]), np.array([c["xstar"]])
+    nk, d = len(c["kerns"]), c["d"]
+    theta = np.concatenate([np.array(c["ls"]).ravel(), c["kv"], c["alpha"], [c["gv"], c["jitter"]]])
+    assert theta.shape == (nk * d + 2 * nk + 2,)
+    return X, y, xs, theta
+
+
+def test_data_gradients_match_mpmath_golden():
+    """dLML/dX, dLML/dy and d mu/dx*, d var/dx* of the oracle against 50-digit numerical differentiation
+    (oracle/gen_golden_data.py): pins the restatements that the device's data-gradient entry points are tested against."""
+    for c in _data_grad_cases():
+        X, y, xs, theta = _case_arrays(c)
+        _, gy, gX = orc.lml_grad_data(X, y, c["kerns"], c["ops"], theta, form="explicit")
+        gX_ref = np.array([[float(v) for v in row] for row in c["gX"]])
+        gy_ref = np.array([float(v) for v in c["gy"]])
+        tol = 1e-7 if "Exponential" in c["kerns"] else 1e-9
+        assert np.abs(gX - gX_ref).max() <= tol * np.abs(gX_ref).max(), c["name"]
+        assert np.abs(gy - gy_ref).max() <= tol * np.abs(gy_ref).max(), c["name"]
+        dmu, dvar = orc.predict_grad(X, y, xs, c["kerns"], c["ops"], theta)
+        dmu_ref = np.array([float(v) for v in c["dmu"]])
+        dvar_ref = np.array([float(v) for v in c["dvar"]])
+        assert np.abs(dmu[0] - dmu_ref).max() <= 10 * tol * max(np.abs(dmu_ref).max(), 1e-300), c["name"]
+        assert np.abs(dvar[0] - dvar_ref).max() <= 10 * tol * max(np.abs(dvar_ref).max(), 1e-300), c["name"]

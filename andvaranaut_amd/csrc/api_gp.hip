@@ -27,6 +27,9 @@ struct mi_gp_handle {
   int lowocc_thr;  // trailing sizes (tile columns) at or below which bulk updates run one workgroup per CU
   int w_thr[3];  // trailing sizes (tile columns) above which the super-panel is 16 / 8 / 4 tiles wide
   std::map<int, hipGraphExec_t> graphs;  // captured evaluation DAGs, keyed by (what, options)
+  std::map<int, float> graph_plain_ms;   // device time of the same evaluation by plain launches, per key
+  int graph_key_last;                    // key replayed by the last evaluation (-1: none) and its slow-replay count
+  int graph_slow_count;
   mi_gp_buffers buf;
   bool have_data;
   // handle-owned small scratch
@@ -112,6 +115,8 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_upd, hipEventDisableTiming);
   h->lookahead = 1;
   h->use_graph = 1;
+  h->graph_key_last = -1;
+  h->graph_slow_count = 0;
   h->bulk_wide = 0;
   h->bulk_wide_late = 0;
   h->bulk_wide_thr = 0;
@@ -405,6 +410,7 @@ static int run_evaluation(mi_gp_handle* h, int what) {
       else hipGraphExecDestroy(exec);
     }
     h->graphs.emplace(key, keep);
+    h->graph_plain_ms[key] = t_plain;
     return download_results(h, what);  // the last run (plain or replay) left valid results
   }
   if (it->second == nullptr) {
@@ -412,7 +418,12 @@ static int run_evaluation(mi_gp_handle* h, int what) {
     if (what == 2) { if (int r = enqueue_gradient(h, false)) return r; }
     return download_results(h, what);
   }
+  // replay, bracketed by two events: factor_internal() compares the device time with the plain-launch time
+  // recorded at capture and drops an executable graph that turns slow (seen once: 6x, ROCm 7.2)
+  (void)hipEventRecord(h->ev[0], h->stream);
   HCK(hipGraphLaunch(it->second, h->stream), "graph launch");
+  (void)hipEventRecord(h->ev[1], h->stream);
+  h->graph_key_last = key;
   return download_results(h, what);
 }
 
@@ -427,8 +438,21 @@ static int factor_internal(mi_gp_handle* h, const double* theta, int what) {
     h->theta_host[i] = theta[i];
   }
   const bool prof = h->prof_level >= 1;
+  h->graph_key_last = -1;
   if (int r = run_evaluation(h, what)) return r;
   HCK(hipStreamSynchronize(h->stream), "stream sync");
+  if (h->graph_key_last >= 0) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, h->ev[0], h->ev[1]) == hipSuccess && ms > 1.5f * h->graph_plain_ms[h->graph_key_last] + 0.05f) {
+      if (++h->graph_slow_count >= 3) {  // three slow replays in a row: fall back to plain launches for this key
+        auto it = h->graphs.find(h->graph_key_last);
+        if (it != h->graphs.end() && it->second) { (void)hipGraphExecDestroy(it->second); it->second = nullptr; }
+        h->graph_slow_count = 0;
+      }
+    } else {
+      h->graph_slow_count = 0;
+    }
+  }
   if (prof) {
     float ms;
     (void)hipEventElapsedTime(&ms, h->ev[0], h->ev[1]); h->t_assemble_ms = ms;

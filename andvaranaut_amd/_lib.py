@@ -69,6 +69,7 @@ def load():
     lib.mi_gp_set_diag.argtypes = [vp, vp]
     lib.mi_gp_factor.argtypes = [vp, dp]
     lib.mi_gp_predict.argtypes = [vp, vp, ci, vp, cl, vp, vp, ci]
+    lib.mi_gp_predict_u.argtypes = [vp, vp, ci, vp, cl, vp, vp, ci]
     lib.mi_gp_predict_grad.argtypes = [vp, vp, ci, vp, cl, vp, vp, ci, vp, vp]
     lib.mi_gp_set_option.argtypes = [vp, ci, ci]
     lib.mi_gp_set_profiling.argtypes = [vp, ci]
@@ -102,6 +103,7 @@ EXPORTS = [
     "mi_gp_set_diag",
     "mi_gp_factor",
     "mi_gp_predict",
+    "mi_gp_predict_u",
     "mi_gp_predict_grad",
     "mi_gp_set_option",
     "mi_gp_set_profiling",

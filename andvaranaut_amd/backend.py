@@ -171,6 +171,8 @@ class MiGP:
         """Factorise for prediction (conditional form); returns LAPACK-style info."""
         theta, tp = self._theta(theta)
         self._factored_ok = False
+        self._u_theta_ok = False
+        self._pred_count = 0
         self.info = self._check(self.lib.mi_gp_factor(self.h, tp), "mi_gp_factor")
         if self.info == 0:
             self._factored_ok, self._factored_theta = True, theta.copy()
@@ -185,30 +187,43 @@ class MiGP:
         if self.factor(theta) != 0:
             raise FloatingPointError(f"covariance not positive definite at pivot {self.info}")
 
-    def predict(self, theta, Xnew, pred_noise=True, chunk=16384):
-        """Posterior mean and diagonal variance at Xnew (converted inputs), chunked over points."""
+    def predict(self, theta, Xnew, pred_noise=True, chunk=16384, via_inverse=None):
+        """Posterior mean and diagonal variance at Xnew (converted inputs), chunked over points.
+        ``via_inverse``: use U = L^-T and one GEMM per chunk (mi_gp_predict_u) instead of the blocked triangular
+        solve; default: when the gradient buffers exist and the sweep is large enough to pay for forming U
+        (or U is already resident from an earlier sweep at this theta)."""
         self._ensure_factored(theta)
         Xnew = np.ascontiguousarray(Xnew, dtype=np.float64)
         if Xnew.ndim != 2 or Xnew.shape[1] != self.d:
             raise ValueError("Xnew must be (m, d)")
         m = Xnew.shape[0]
+        if via_inverse is None:
+            # U pays off for a large sweep, when it is already there, or from the third sweep on the same factor
+            # (differential-evolution generations, refinement steps)
+            self._pred_count = getattr(self, "_pred_count", 0) + 1
+            via_inverse = self.Z_t is not None and (getattr(self, "_u_theta_ok", False) or 3 * m >= self.n
+                                                    or self._pred_count >= 3)
+        if via_inverse and self.Z_t is None:
+            raise RuntimeError("this MiGP was created with need_grad=False")
         mean = np.empty(m)
         var = np.empty(m)
         with torch.cuda.device(self.dev):
             for s in range(0, m, chunk):
                 mc = min(chunk, m - s)
                 mp = (mc + 127) // 128 * 128
-                if getattr(self, "_work", None) is None or self._work.shape[0] < mp:
-                    self._work = torch.empty((mp, self.lda), dtype=torch.float64, device=self.dev)
+                rows = 2 * mp if via_inverse else mp
+                if getattr(self, "_work", None) is None or self._work.shape[0] < rows:
+                    self._work = torch.empty((rows, self.lda), dtype=torch.float64, device=self.dev)
                 xn = torch.from_numpy(Xnew[s : s + mc]).to(self.dev)
                 mu_t = torch.empty(mc, dtype=torch.float64, device=self.dev)
                 var_t = torch.empty(mc, dtype=torch.float64, device=self.dev)
                 torch.cuda.synchronize(self.dev)
-                self._check(
-                    self.lib.mi_gp_predict(self.h, xn.data_ptr(), mc, self._work.data_ptr(), self.lda, mu_t.data_ptr(),
-                                           var_t.data_ptr(), 1 if pred_noise else 0),
-                    "mi_gp_predict",
-                )
+                fn = self.lib.mi_gp_predict_u if via_inverse else self.lib.mi_gp_predict
+                self._check(fn(self.h, xn.data_ptr(), mc, self._work.data_ptr(), self.lda, mu_t.data_ptr(),
+                               var_t.data_ptr(), 1 if pred_noise else 0),
+                            "mi_gp_predict_u" if via_inverse else "mi_gp_predict")
+                if via_inverse:
+                    self._u_theta_ok = True
                 mean[s : s + mc] = mu_t.cpu().numpy()
                 var[s : s + mc] = var_t.cpu().numpy()
         return mean, var

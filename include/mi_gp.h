@@ -97,6 +97,12 @@ int mi_gp_factor(mi_gp_handle* h, const double* theta_host);
  * ceil(m/128)*128 rows x ldw (ldw even, >= mi_gp_padded_n()); mean_dev / var_dev receive m doubles. */
 int mi_gp_predict(mi_gp_handle* h, const double* Xnew_dev, int m, double* work_dev, long ldw, double* mean_dev,
                   double* var_dev, int pred_noise);
+/* The same conditional through U = L^-T (formed once per mi_gp_factor, N^3/3 flops): A = K(X*, X) U is one GEMM with
+ * a triangular k-range instead of the blocked triangular solve -- the path for sweeps of many points at fixed
+ * hyper-parameters (BO's 10 000-point proposals at gpmcmc.py:691-697).  Needs Z_dev / W_dev; work_dev must hold
+ * 2 * ceil(m/128)*128 rows x ldw. */
+int mi_gp_predict_u(mi_gp_handle* h, const double* Xnew_dev, int m, double* work_dev, long ldw, double* mean_dev,
+                    double* var_dev, int pred_noise);
 /* The same plus d mu / d x* and d var / d x* (m x d each, device): d mu = sum_i alpha_i dk(x_i,x*)/dx*,
  * d var = -2 sum_i w_i dk(x_i,x*)/dx* with w = K^-1 k(X,x*).  Replaces the PyTensor graph of the single-point
  * predictive that BO's refinement differentiates (gpmcmc.py:766-801).  Needs Z_dev / W_dev; work_dev must hold

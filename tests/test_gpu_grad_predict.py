@@ -143,3 +143,25 @@ def test_interpolation_property_at_training_points():
     assert np.abs(mu - y).max() < 2e-2  # residual = gv * alpha, small but not zero (y carries noise)
     assert np.all(var > 0) and var.max() < 1e-6
     gp.close()
+
+
+@pytest.mark.parametrize("N,d,kernel,M", [(1, 1, "RBF", 3), (300, 3, "Matern52", 700), (1000, 4, "Matern32+RBF", 129), (2500, 6, "RBF", 5000)])
+def test_predict_through_the_inverse_factor_matches_oracle(N, d, kernel, M):
+    """mi_gp_predict_u (A = K* U as one GEMM) against the oracle's conditional and against the triangular-solve path."""
+    MiGP, orc = _mods()
+    X, y = orc.synth_problem(max(N, 3), d, seed=N + d)
+    X, y = X[:N], y[:N]
+    kerns, ops = _split(kernel)
+    theta = orc.synth_theta(d, nkern=len(kerns), gv=1e-3)
+    Xn = np.random.default_rng(M).uniform(0.0, 1.0, (M, d))
+    gp = MiGP(X, y, kernel)
+    mu_u, var_u = gp.predict(theta, Xn, via_inverse=True)
+    mu_t, var_t = gp.predict(theta, Xn, via_inverse=False)
+    mu_o, var_o = orc.predict(X, y, Xn, kerns, ops, theta)
+    assert np.allclose(mu_u, mu_o, rtol=1e-8, atol=1e-9) and np.allclose(var_u, var_o, rtol=1e-7, atol=1e-10)
+    assert np.allclose(mu_u, mu_t, rtol=1e-9, atol=1e-10) and np.allclose(var_u, var_t, rtol=1e-8, atol=1e-11)
+    # default routing: large sweeps go through U, and an LML evaluation in between invalidates it
+    gp.lml(theta)
+    mu_d, _ = gp.predict(theta, Xn)
+    assert np.allclose(mu_d, mu_o, rtol=1e-8, atol=1e-9)
+    gp.close()

@@ -71,11 +71,12 @@ __global__ __launch_bounds__(256) void assemble_kernel(KernSpec spec, const doub
     for (int m0 = 0; m0 < d; m0 += DCH) {
       const int dc = min(DCH, d - m0);
       __syncthreads();
-      for (int e = tid; e < AT * DCH; e += 256) {
-        const int r = e / DCH, m = e % DCH;
+      // 256 % DCH == 0: a thread always stages the same input dimension m, so its 1/l is one division per chunk
+      const int m = tid % DCH;
+      const double il = (m < dc) ? 1.0 / ls[c * d + m0 + m] : 0.0;
+      for (int r = tid / DCH; r < AT; r += 256 / DCH) {
         double vi = 0.0, vj = 0.0;
         if (m < dc) {
-          const double il = 1.0 / ls[c * d + m0 + m];
           if (i0 + r < n1) vi = X1[(long)(i0 + r) * d + m0 + m] * il;
           if (j0 + r < n2) vj = X2[(long)(j0 + r) * d + m0 + m] * il;
         }

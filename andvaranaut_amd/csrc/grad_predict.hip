@@ -161,16 +161,18 @@ __global__ __launch_bounds__(256) void grad_contract_kernel(KernSpec spec, const
     for (int m0 = 0; m0 < d; m0 += GDCH) {
       const int dc = min(GDCH, d - m0);
       __syncthreads();
-      for (int e = tid; e < GT * GDCH; e += 256) {
-        const int r = e / GDCH, m = e % GDCH;
-        double vi = 0.0, vj = 0.0;
-        if (m < dc) {
-          const double il = 1.0 / ls[c * d + m0 + m];
-          if (i0 + r < n) vi = X[(long)(i0 + r) * d + m0 + m] * il;
-          if (j0 + r < n) vj = X[(long)(j0 + r) * d + m0 + m] * il;
+      {  // 256 % GDCH == 0: a thread always stages the same input dimension, one division per chunk
+        const int m = tid % GDCH;
+        const double il = (m < dc) ? 1.0 / ls[c * d + m0 + m] : 0.0;
+        for (int r = tid / GDCH; r < GT; r += 256 / GDCH) {
+          double vi = 0.0, vj = 0.0;
+          if (m < dc) {
+            if (i0 + r < n) vi = X[(long)(i0 + r) * d + m0 + m] * il;
+            if (j0 + r < n) vj = X[(long)(j0 + r) * d + m0 + m] * il;
+          }
+          Xi[r * GDLD + m] = vi;
+          Xj[r * GDLD + m] = vj;
         }
-        Xi[r * GDLD + m] = vi;
-        Xj[r * GDLD + m] = vj;
       }
       __syncthreads();
       for (int m = 0; m < dc; ++m) {
@@ -271,16 +273,18 @@ __global__ __launch_bounds__(256) void grad_contract_kernel(KernSpec spec, const
     for (int m0 = 0; m0 < d; m0 += GDCH) {
       const int dc = min(GDCH, d - m0);
       __syncthreads();
-      for (int e = tid; e < GT * GDCH; e += 256) {
-        const int r = e / GDCH, m = e % GDCH;
-        double vi = 0.0, vj = 0.0;
-        if (m < dc) {
-          const double il = 1.0 / ls[c * d + m0 + m];
-          if (i0 + r < n) vi = X[(long)(i0 + r) * d + m0 + m] * il;
-          if (j0 + r < n) vj = X[(long)(j0 + r) * d + m0 + m] * il;
+      {  // 256 % GDCH == 0: a thread always stages the same input dimension, one division per chunk
+        const int m = tid % GDCH;
+        const double il = (m < dc) ? 1.0 / ls[c * d + m0 + m] : 0.0;
+        for (int r = tid / GDCH; r < GT; r += 256 / GDCH) {
+          double vi = 0.0, vj = 0.0;
+          if (m < dc) {
+            if (i0 + r < n) vi = X[(long)(i0 + r) * d + m0 + m] * il;
+            if (j0 + r < n) vj = X[(long)(j0 + r) * d + m0 + m] * il;
+          }
+          Xi[r * GDLD + m] = vi;
+          Xj[r * GDLD + m] = vj;
         }
-        Xi[r * GDLD + m] = vi;
-        Xj[r * GDLD + m] = vj;
       }
       __syncthreads();
       for (int m = 0; m < dc; ++m) {

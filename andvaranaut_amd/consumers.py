@@ -281,7 +281,7 @@ class ConsumersMixin:
                             # the reference draws these with scipy's "random-cd" discrepancy optimisation
                             # (lhc.py:42), 14 s of host time for 10 000 points; a plain Latin hypercube serves an
                             # arg-min sweep as well and keeps the iteration on the device's time scale
-                            xsamps = latin_sample(self.priors, predict_samps,
+                            xsamps = latin_sample(self.priors, predict_samps, seed=int(np.random.randint(2 ** 31 - 1)),
                                                   optimization="random-cd" if predict_samps <= 2000 else None)
                             ysamps = optf(xsamps)
                             xsamp, fopt = np.array([xsamps[np.argmin(ysamps), :]]), np.min(ysamps)

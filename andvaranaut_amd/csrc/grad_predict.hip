@@ -287,6 +287,8 @@ __global__ __launch_bounds__(256) void grad_contract_kernel(KernSpec spec, const
         }
       }
       __syncthreads();
+      // per-dimension sums: wave partials of all dimensions of the chunk go to LDS, ONE barrier, then thread m adds
+      // its four (same order as a per-dimension block sum, two barriers per dimension less)
       for (int m = 0; m < dc; ++m) {
         double xi[4], xj[4];
 #pragma unroll
@@ -301,8 +303,13 @@ __global__ __launch_bounds__(256) void grad_contract_kernel(KernSpec spec, const
             const double df = xi[a] - xj[b];
             s += wc[c][a][b] * dkv[c][a][b] * (df * df);
           }
-        s = block_sum(s);
-        if (tid == 0) out[c * d + m0 + m] = s * (-2.0 / ls[c * d + m0 + m]);
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if ((tid & 63) == 0) red[4 * m + (tid >> 6)] = s;
+      }
+      __syncthreads();
+      if (tid < dc) {
+        const double s = red[4 * tid] + red[4 * tid + 1] + red[4 * tid + 2] + red[4 * tid + 3];
+        out[c * d + m0 + tid] = s * (-2.0 / ls[c * d + m0 + tid]);
       }
     }
   }

@@ -79,6 +79,11 @@ def load():
     lib.mi_gp_chol_panel.argtypes = [vp, cl, ci, ci, vp, vp, ci, vp]
     lib.mi_gp_lml_partial.argtypes = [vp, cl, vp, ci, vp, vp]
     lib.mi_gp_gemm_f64.argtypes = [ci, ci, ci, ci, ci, cd, vp, cl, vp, cl, cd, vp, cl, ci, ci, ci, cl, cl, cl, vp]
+    lib.mi_gp_trsm_block.argtypes = [vp, cl, vp, ci, ci, vp, cl, ci, vp]
+    lib.mi_gp_trmv_upper.argtypes = [vp, cl, vp, ci, vp, vp]
+    lib.mi_gp_grad_contract_block_scratch.argtypes = [ci, ci, ci, ci]
+    lib.mi_gp_grad_contract_block_scratch.restype = cl
+    lib.mi_gp_grad_contract_block.argtypes = [ci, ci, ip, ip, vp, vp, ci, vp, cl, ci, ci, ci, vp, vp, cl, vp, vp]
     for name in EXPORTS:
         getattr(lib, name)  # raises AttributeError if a declared symbol is missing
     _lib = lib
@@ -112,4 +117,8 @@ EXPORTS = [
     "mi_gp_assemble_block",
     "mi_gp_chol_panel",
     "mi_gp_lml_partial",
+    "mi_gp_trsm_block",
+    "mi_gp_trmv_upper",
+    "mi_gp_grad_contract_block_scratch",
+    "mi_gp_grad_contract_block",
 ]

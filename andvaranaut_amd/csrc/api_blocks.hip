@@ -113,3 +113,73 @@ extern "C" int mi_gp_lml_partial(const double* L_dev, long ld, const double* bet
   if (e != hipSuccess) return fail(e, "lml_partial");
   return 0;
 }
+
+// ---------------------------------------------------------------- sharded gradient building blocks (third row)
+// X L^T = B in place for tile columns [c0, c0 + w) of the factor; B points at the first of those columns
+static hipError_t trsm_block_rec(const double* L, long ldl, const double* dinv, double* B, long ldb, int m, int cbase,
+                                 int c0, int w, hipStream_t st) {
+  if (w == 1)
+    return launch_trsm_strip128(L + (long)c0 * 128 * ldl + (long)c0 * 128, ldl, dinv + (size_t)c0 * 2048,
+                                B + (long)(c0 - cbase) * 128, ldb, m, st);
+  const int w1 = w / 2, w2 = w - w1;
+  hipError_t e = trsm_block_rec(L, ldl, dinv, B, ldb, m, cbase, c0, w1, st);
+  if (e != hipSuccess) return e;
+  // B[:, c0+w1 : c0+w) -= X[:, c0 : c0+w1) * L[c0+w1 : c0+w, c0 : c0+w1)^T
+  GemmParams p;
+  p.A = B + (long)(c0 - cbase) * 128;
+  p.B = L + (long)(c0 + w1) * 128 * ldl + (long)c0 * 128;
+  p.C = B + (long)(c0 + w1 - cbase) * 128;
+  p.lda = ldb; p.ldb = ldl; p.ldc = ldb;
+  p.strideA = p.strideB = p.strideC = 0;
+  p.mt = m / 128; p.nt = w2; p.k = w1 * 128; p.tri = 0; p.kmode = 0; p.alpha = -1.0; p.beta = 1.0;
+  e = launch_gemm_f64(p, 0, 0, 1, st);
+  if (e != hipSuccess) return e;
+  return trsm_block_rec(L, ldl, dinv, B, ldb, m, cbase, c0 + w1, w2, st);
+}
+
+extern "C" int mi_gp_trsm_block(const double* L_dev, long ldl, const double* dinv_dev, int c0_tiles, int w_tiles,
+                                double* B_dev, long ldb, int m, void* stream) {
+  if (!L_dev || !dinv_dev || !B_dev || c0_tiles < 0 || w_tiles <= 0 || m <= 0 || m % 128 || (ldl & 1) || (ldb & 1)) {
+    snprintf(g_err, sizeof(g_err), "mi_gp_trsm_block: bad argument (m multiple of 128, even leading dimensions)");
+    return -1;
+  }
+  if (int r = ensure_init()) return r;
+  hipError_t e = trsm_block_rec(L_dev, ldl, dinv_dev, B_dev, ldb, m, c0_tiles, c0_tiles, w_tiles, (hipStream_t)stream);
+  if (e != hipSuccess) return fail(e, "trsm_block");
+  return 0;
+}
+
+extern "C" int mi_gp_trmv_upper(const double* U_dev, long ld, const double* x_dev, int n, double* out_dev, void* stream) {
+  if (!U_dev || !x_dev || !out_dev || n <= 0) {
+    snprintf(g_err, sizeof(g_err), "mi_gp_trmv_upper: bad argument");
+    return -1;
+  }
+  hipError_t e = launch_trmv_upper(U_dev, ld, x_dev, n, out_dev, (hipStream_t)stream);
+  if (e != hipSuccess) return fail(e, "trmv_upper");
+  return 0;
+}
+
+extern "C" long mi_gp_grad_contract_block_scratch(int n, int col0, int cols, int ntheta) {
+  return (long)grad_contract_slab_blocks(n, col0, cols) * ntheta;
+}
+
+extern "C" int mi_gp_grad_contract_block(int d, int nkern, const int* kernel_ids, const int* ops, const double* theta_dev,
+                                         const double* X_dev, int n, const double* W_dev, long ldw, int row0, int col0,
+                                         int cols, const double* alpha_dev, double* part_dev, long part_len,
+                                         double* grad_dev, void* stream) {
+  if (d <= 0 || nkern <= 0 || nkern > MAX_KERN || !theta_dev || !X_dev || !W_dev || !alpha_dev || !part_dev || !grad_dev ||
+      n <= 0 || row0 < 0 || row0 > col0 || col0 % 64 || row0 % 64 || cols <= 0 || cols % 64) {
+    snprintf(g_err, sizeof(g_err), "mi_gp_grad_contract_block: bad argument (row0 <= col0, multiples of 64)");
+    return -1;
+  }
+  const int ntheta = nkern * d + 2 * nkern + 2;
+  if (part_len < (long)grad_contract_slab_blocks(n, col0, cols) * ntheta) {
+    snprintf(g_err, sizeof(g_err), "mi_gp_grad_contract_block: scratch shorter than mi_gp_grad_contract_block_scratch()");
+    return -1;
+  }
+  const KernSpec spec = make_spec(d, nkern, kernel_ids, ops);
+  hipError_t e = launch_grad_contract_slab(spec, theta_dev, X_dev, n, W_dev, ldw, row0, col0, cols, alpha_dev, part_dev,
+                                           grad_dev, (hipStream_t)stream);
+  if (e != hipSuccess) return fail(e, "grad_contract_block");
+  return 0;
+}

@@ -407,7 +407,7 @@ static int run_evaluation(mi_gp_handle* h, int what) {
       HCK(hipStreamSynchronize(h->stream), "sync");
       (void)hipEventElapsedTime(&t_graph, h->ev[0], h->ev[1]);
       if (t_graph <= 1.05f * t_plain) keep = exec;
-      else hipGraphExecDestroy(exec);
+      else (void)hipGraphExecDestroy(exec);
     }
     h->graphs.emplace(key, keep);
     h->graph_plain_ms[key] = t_plain;

@@ -111,13 +111,27 @@ __global__ __launch_bounds__(256) void grad_contract_kernel(KernSpec spec, const
                                                             const double* __restrict__ X, int n,
                                                             const double* __restrict__ W, long ldw,
                                                             const double* __restrict__ alpha_v,
-                                                            double* __restrict__ part) {
+                                                            double* __restrict__ part, int rect_tw, int tj0,
+                                                            long wrow0, long wcol0) {
   __shared__ double Xi[GT * GDLD];
   __shared__ double Xj[GT * GDLD];
   __shared__ double red[256];
   const int tid = threadIdx.x;
+  const int d = spec.d;
+  const int P = NK * d + 2 * NK + 2;
+  double* out = part + (long)blockIdx.x * P;
   int ti, tj;
-  {
+  if (rect_tw > 0) {
+    // column slab of a distributed K^-1: tile columns [tj0, tj0 + rect_tw), tile rows from tj0 down; W holds the slab
+    // with its element (wrow0, wcol0) first.  Tiles above the diagonal contribute nothing.
+    ti = tj0 + blockIdx.x / rect_tw;
+    tj = tj0 + blockIdx.x % rect_tw;
+    if (ti < tj) {
+      for (int p = tid; p < P; p += 256) out[p] = 0.0;
+      return;
+    }
+    W -= wrow0 * ldw + wcol0;
+  } else {
     const int e = blockIdx.x;
     int t = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
     while ((t + 1) * (t + 2) / 2 <= e) ++t;
@@ -127,12 +141,9 @@ __global__ __launch_bounds__(256) void grad_contract_kernel(KernSpec spec, const
   }
   const int i0 = ti * GT, j0 = tj * GT;
   const int tx = tid & 15, ty = tid >> 4;
-  const int d = spec.d;
   const double* ls = theta;
   const double* kv = theta + NK * d;
   const double* al = kv + NK;
-  const int P = NK * d + 2 * NK + 2;
-  double* out = part + (long)blockIdx.x * P;
 
   // weights: w_ab = (alpha_i alpha_j - W_ij) * (1 below the diagonal, 1/2 on it, 0 above / padding)
   double wgt[4][4];
@@ -563,10 +574,38 @@ hipError_t launch_grad_contract(const KernSpec& spec, const double* theta, const
   const int nblk = grad_contract_blocks(n);
   const int P = spec.nkern * spec.d + 2 * spec.nkern + 2;
   switch (spec.nkern) {
-    case 1: grad_contract_kernel<1><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part); break;
-    case 2: grad_contract_kernel<2><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part); break;
-    case 3: grad_contract_kernel<3><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part); break;
-    default: grad_contract_kernel<4><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part); break;
+    case 1: grad_contract_kernel<1><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, 0, 0, 0, 0); break;
+    case 2: grad_contract_kernel<2><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, 0, 0, 0, 0); break;
+    case 3: grad_contract_kernel<3><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, 0, 0, 0, 0); break;
+    default: grad_contract_kernel<4><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, 0, 0, 0, 0); break;
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  grad_final_kernel<<<P, 256, 0, stream>>>(part, nblk, P, grad);
+  return hipGetLastError();
+}
+
+// Column slab [col0, col0 + cols) of the lower triangle (rows >= col0): W points at element (row0, col0) of K^-1,
+// row0 <= col0, both multiples of 64.  part: grad_contract_slab_blocks() x ntheta doubles.
+int grad_contract_slab_blocks(int n, int col0, int cols) {
+  const int nt = (n + GT - 1) / GT;
+  const int tj0 = col0 / GT, tw = min((cols + GT - 1) / GT, nt - tj0);
+  return tw <= 0 ? 0 : (nt - tj0) * tw;
+}
+
+hipError_t launch_grad_contract_slab(const KernSpec& spec, const double* theta, const double* X, int n, const double* W,
+                                     long ldw, int row0, int col0, int cols, const double* alpha, double* part,
+                                     double* grad, hipStream_t stream) {
+  const int nt = (n + GT - 1) / GT;
+  const int tj0 = col0 / GT, tw = min((cols + GT - 1) / GT, nt - tj0);
+  const int P = spec.nkern * spec.d + 2 * spec.nkern + 2;
+  if (tw <= 0) return hipMemsetAsync(grad, 0, sizeof(double) * P, stream);
+  const int nblk = (nt - tj0) * tw;
+  switch (spec.nkern) {
+    case 1: grad_contract_kernel<1><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, tw, tj0, row0, col0); break;
+    case 2: grad_contract_kernel<2><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, tw, tj0, row0, col0); break;
+    case 3: grad_contract_kernel<3><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, tw, tj0, row0, col0); break;
+    default: grad_contract_kernel<4><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, tw, tj0, row0, col0); break;
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;

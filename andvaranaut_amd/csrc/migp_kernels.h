@@ -73,6 +73,11 @@ int grad_contract_blocks(int n);
 // part: [grad_contract_blocks(n)][ntheta] scratch; grad: [ntheta] (natural parameters, C-ABI order)
 hipError_t launch_grad_contract(const KernSpec& spec, const double* theta, const double* X, int n, const double* W,
                                 long ldw, const double* alpha, double* part, double* grad, hipStream_t stream);
+// column slab [col0, col0+cols) of the lower triangle (distributed K^-1): W points at element (row0, col0), row0 <= col0
+int grad_contract_slab_blocks(int n, int col0, int cols);
+hipError_t launch_grad_contract_slab(const KernSpec& spec, const double* theta, const double* X, int n, const double* W,
+                                     long ldw, int row0, int col0, int cols, const double* alpha, double* part,
+                                     double* grad, hipStream_t stream);
 // gx: [n][d] dLML/dX from Kinv (lower triangle in W) and alpha; d <= 128
 int grad_x_splits(int n, int d);  // column splits; scratch of [splits][n][d] doubles is needed when > 1
 hipError_t launch_grad_x(const KernSpec& spec, const double* theta, const double* X, int n, const double* W, long ldw,

@@ -8,7 +8,17 @@ posted before the bulk updates, so the transfer overlaps them.
 Only the exchange step is a collective (one broadcast per panel, two scalars all-reduced at the
 end); assembly is local (X is replicated, 8*N*d bytes).  All arithmetic runs in the same HIP kernels
 as the single-GPU path, reached through the block-level C-ABI entry points
-(mi_gp_assemble_block, mi_gp_chol_panel, mi_gp_gemm_f64, mi_gp_lml_partial)."""
+(mi_gp_assemble_block, mi_gp_chol_panel, mi_gp_gemm_f64, mi_gp_lml_partial).
+
+The gradient (section 8e, third row) shards K^-1 the same way.  Every rank keeps the panels it receives, so the
+complete factor L is resident everywhere at no extra traffic (288 GB of HBM: 34 GB at N = 65536).  Then
+  1. rows J of U = L^-T for the owned panels J: a right-side triangular solve against L with rows J of the
+     identity (mi_gp_trsm_block) -- N^3/3 flops in total, split evenly by the block-cyclic ownership, no exchange;
+  2. ONE exchange: each row panel of U is broadcast by its owner (upper part only, 4*N^2 bytes in total);
+  3. the owned column slabs of K^-1 = U U^T (one triangular-k GEMM per slab, N^3/3 flops in total), alpha = U beta
+     (replicated, bandwidth-bound), and the slab's share of 1/2 tr((alpha alpha^T - K^-1) dK/dtheta)
+     (mi_gp_grad_contract_block);
+  4. one all-reduce of the ntheta partial sums."""
 import ctypes
 import math
 
@@ -20,6 +30,7 @@ from . import _lib
 from .backend import parse_kernel
 
 PW_TILES = 4  # super-panel width in 128-column tiles
+DINV_ROWS = 16  # PW_TILES * 2048 leaf-inverse doubles appended to a broadcast panel (rows of PW_TILES*128 doubles)
 
 
 class DistGP:
@@ -52,7 +63,7 @@ class DistGP:
             self.X_t = torch.from_numpy(X).to(self.dev)
             self.y_t = torch.from_numpy(y).to(self.dev)
             self.K = torch.zeros((rows, self.ld), dtype=torch.float64, device=self.dev)
-            self.P = [torch.zeros((rows, self.ldbuf), dtype=torch.float64, device=self.dev) for _ in range(2)]
+            self.P = [torch.zeros((rows + DINV_ROWS, self.ldbuf), dtype=torch.float64, device=self.dev) for _ in range(2)]
             self.theta_t = torch.zeros(self.ntheta, dtype=torch.float64, device=self.dev)
             self.dinv = torch.zeros(PW_TILES * 2048, dtype=torch.float64, device=self.dev)
             self.info = torch.zeros(4, dtype=torch.int32, device=self.dev)
@@ -111,13 +122,17 @@ class DistGP:
         r0 = j * self.pw
         rows = self.np_ + 128 - r0
         buf[:rows, : w * 128].copy_(self.K[r0:, li * self.pw: li * self.pw + w * 128])
+        # the leaf inverses travel with the panel (16 more rows): the gradient's triangular solves need them everywhere
+        buf[rows: rows + DINV_ROWS].view(-1)[: w * 2048].copy_(self.dinv[: w * 2048])
 
     # ------------------------------------------------------------------ evaluation
-    def lml(self, theta, noise_form=0):
+    def lml(self, theta, noise_form=0, _keep=False):
         """LML at natural-scale theta (C-ABI layout); -inf if the covariance is not positive definite."""
         theta = np.ascontiguousarray(theta, dtype=np.float64)
         if theta.shape != (self.ntheta,):
             raise ValueError(f"theta must have {self.ntheta} entries")
+        if _keep:
+            self._alloc_grad_buffers()
         with torch.cuda.device(self.dev):
             self.theta_t.copy_(torch.from_numpy(theta))
             self.info.fill_(0x7F7F7F7F)
@@ -132,6 +147,8 @@ class DistGP:
                 buf = self.P[j % 2]
                 if work is not None:
                     work.wait()
+                if _keep:
+                    self._keep_panel(j, buf)
                 jn = j + 1
                 work = None
                 if jn < self.npan:
@@ -169,6 +186,99 @@ class DistGP:
     def _bcast(self, j):
         if self.world == 1:
             return None
-        rows = self.np_ + 128 - j * self.pw
+        rows = self.np_ + 128 - j * self.pw + DINV_ROWS
         view = self.P[j % 2][:rows]  # contiguous leading rows of the panel buffer
         return dist.broadcast(view, src=j % self.world, async_op=True)
+
+    # ------------------------------------------------------------------ gradient
+    def _alloc_grad_buffers(self):
+        if getattr(self, "Lf", None) is not None:
+            return
+        with torch.cuda.device(self.dev):
+            self.ldf = self.np_ + 16
+            self.Lf = torch.zeros((self.np_, self.ldf), dtype=torch.float64, device=self.dev)   # complete factor
+            self.Uf = torch.zeros((self.np_, self.ldf), dtype=torch.float64, device=self.dev)   # complete U = L^-T
+            self.dinv_f = torch.zeros(self.ntc * 2048, dtype=torch.float64, device=self.dev)
+            self.beta_f = torch.zeros(self.np_, dtype=torch.float64, device=self.dev)
+            self.alpha_f = torch.zeros(self.np_, dtype=torch.float64, device=self.dev)
+            self.W = torch.zeros((self.np_, self.ldbuf), dtype=torch.float64, device=self.dev)  # one K^-1 column slab
+            self.UP = [torch.zeros(self.pw * self.np_, dtype=torch.float64, device=self.dev) for _ in range(2)]
+            nsc = self.lib.mi_gp_grad_contract_block_scratch(self.n, 0, self.pw, self.ntheta)
+            self.part = torch.zeros(max(int(nsc), 1), dtype=torch.float64, device=self.dev)
+            self.gslab = torch.zeros(self.ntheta, dtype=torch.float64, device=self.dev)
+
+    def _keep_panel(self, j, buf):
+        w = self._w(j)
+        r0 = j * self.pw
+        rows = self.np_ - r0
+        self.Lf[r0:, r0: r0 + w * 128].copy_(buf[:rows, : w * 128])
+        self.dinv_f[j * PW_TILES * 2048: (j * PW_TILES + w) * 2048].copy_(
+            buf[rows + 128: rows + 128 + DINV_ROWS].view(-1)[: w * 2048])
+        nv = max(0, min(self.n - r0, w * 128))  # beta = L^-1 y rides in the first row of the panel's y block
+        self.beta_f[r0: r0 + nv].copy_(buf[rows, :nv])
+
+    def _u_rows(self, j):
+        """rows of panel j of U = L^-T, in place in the complete U: X L^T = (rows j of I) over the columns from j on."""
+        w = self._w(j)
+        r0 = j * self.pw
+        blk = self.Uf[r0: r0 + w * 128]
+        blk.zero_()
+        torch.diagonal(blk, offset=r0).fill_(1.0)
+        self._check(self.lib.mi_gp_trsm_block(self.Lf.data_ptr(), self.ldf, self.dinv_f.data_ptr(), j * PW_TILES,
+                                              self.ntc - j * PW_TILES, self._ptr(self.Uf, r0, r0), self.ldf, w * 128,
+                                              self._stream()), "mi_gp_trsm_block")
+
+    def lml_grad(self, theta):
+        """(LML, dLML/dtheta) at natural-scale theta, C-ABI parameter order; (-inf, zeros) if K is not positive definite.
+        Same values on every rank."""
+        val = self.lml(theta, 0, _keep=True)
+        grad = np.zeros(self.ntheta)
+        if not np.isfinite(val):
+            return val, grad
+        with torch.cuda.device(self.dev):
+            # 1. owned row panels of U
+            for j in self.own:
+                self._u_rows(j)
+            # 2. the exchange: upper part of each row panel, packed, from its owner (two buffers in flight)
+            if self.world > 1:
+                pending = []
+                for j in range(self.npan):
+                    w, r0 = self._w(j), j * self.pw
+                    cols = self.np_ - r0
+                    pk = self.UP[j % 2][: w * 128 * cols].view(w * 128, cols)
+                    if len(pending) == 2:
+                        self._finish_u(*pending.pop(0))
+                    if j % self.world == self.rank:
+                        pk.copy_(self.Uf[r0: r0 + w * 128, r0: self.np_])
+                    pending.append((j, pk, dist.broadcast(pk, src=j % self.world, async_op=True)))
+                while pending:
+                    self._finish_u(*pending.pop(0))
+            # 3. alpha = U beta (replicated), then slab by slab: K^-1[:, J] = U[J:, :] U[J, :]^T and its share of the trace
+            self._check(self.lib.mi_gp_trmv_upper(self.Uf.data_ptr(), self.ldf, self.beta_f.data_ptr(), self.n,
+                                                  self.alpha_f.data_ptr(), self._stream()), "mi_gp_trmv_upper")
+            gsum = torch.zeros(self.ntheta, dtype=torch.float64, device=self.dev)
+            for j in self.own:
+                w, r0 = self._w(j), j * self.pw
+                if r0 >= self.n:
+                    continue  # padding only
+                m = self.np_ - r0
+                a_ptr = self._ptr(self.Uf, r0, r0)
+                self._check(self.lib.mi_gp_gemm_f64(0, 1, m, w * 128, m, 1.0, a_ptr, self.ldf, a_ptr, self.ldf, 0.0,
+                                                    self.W.data_ptr(), self.ldbuf, 1, 3, 1, 0, 0, 0, self._stream()),
+                            "mi_gp_gemm_f64")
+                self._check(self.lib.mi_gp_grad_contract_block(
+                    self.d, self.nkern, self.kids, self.opids, self.theta_t.data_ptr(), self.X_t.data_ptr(), self.n,
+                    self.W.data_ptr(), self.ldbuf, r0, r0, w * 128, self.alpha_f.data_ptr(), self.part.data_ptr(),
+                    self.part.numel(), self.gslab.data_ptr(), self._stream()), "mi_gp_grad_contract_block")
+                gsum += self.gslab
+            # 4. one small all-reduce
+            if self.world > 1:
+                dist.all_reduce(gsum, op=dist.ReduceOp.SUM)
+            grad = gsum.cpu().numpy()
+        return val, grad
+
+    def _finish_u(self, j, pk, work):
+        work.wait()
+        if j % self.world != self.rank:
+            w, r0 = self._w(j), j * self.pw
+            self.Uf[r0: r0 + w * 128, r0: self.np_].copy_(pk)

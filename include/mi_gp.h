@@ -159,6 +159,29 @@ int mi_gp_chol_panel(double* A_dev, long lda, int row_tiles, int w_tiles, double
 /* out_dev[1] = sum_i log L[i][i], out_dev[2] = sum_i beta[i]^2 over n entries (one workgroup). */
 int mi_gp_lml_partial(const double* L_dev, long ld, const double* beta_dev, int n, double* out_dev, void* hip_stream);
 
+/* ---- sharded gradient ("gradient at C4 scale needs distributed K^-1"): the reference gets dLML/dtheta from
+ * pytensor.grad through Cholesky.L_op behind pm.find_MAP / pm.sample (gpmcmc.py:345,351); the sharded driver
+ * (andvaranaut_amd/distributed.py) builds it from these blocks. */
+
+/* X L^T = B in place (X = B L^-T) for the 128-column tiles [c0_tiles, c0_tiles + w_tiles) of a complete lower factor
+ * L_dev (element (0,0) first, leading dimension ldl); dinv_dev: the 2048-double leaf inverses mi_gp_chol_panel wrote,
+ * indexed by global tile; B_dev points at the first of those columns of the m-row right-hand side (m multiple of 128).
+ * With B = rows J of the identity this yields rows J of U = L^-T.  LAPACK dtrsm('R','L','T','N'). */
+int mi_gp_trsm_block(const double* L_dev, long ldl, const double* dinv_dev, int c0_tiles, int w_tiles, double* B_dev,
+                     long ldb, int m, void* hip_stream);
+
+/* out = U x for an upper-triangular n x n U (alpha = L^-T beta, gpmcmc.py:315). */
+int mi_gp_trmv_upper(const double* U_dev, long ld, const double* x_dev, int n, double* out_dev, void* hip_stream);
+
+/* grad_dev[ntheta] = 1/2 sum (alpha_i alpha_j - Kinv_ij) dK_ij/dtheta over the column slab [col0, col0 + cols) of the
+ * lower triangle (rows >= col0; diagonal counted once).  W_dev points at element (row0, col0) of K^-1 (row0 <= col0,
+ * all multiples of 64); part_dev: mi_gp_grad_contract_block_scratch() doubles.  Slab sums add up to mi_gp_lml_grad's. */
+long mi_gp_grad_contract_block_scratch(int n, int col0, int cols, int ntheta);
+int mi_gp_grad_contract_block(int d, int nkern, const int* kernel_ids, const int* ops, const double* theta_dev,
+                              const double* X_dev, int n, const double* W_dev, long ldw, int row0, int col0, int cols,
+                              const double* alpha_dev, double* part_dev, long part_len, double* grad_dev,
+                              void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

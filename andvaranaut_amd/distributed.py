@@ -202,6 +202,7 @@ class DistGP:
             self.beta_f = torch.zeros(self.np_, dtype=torch.float64, device=self.dev)
             self.alpha_f = torch.zeros(self.np_, dtype=torch.float64, device=self.dev)
             self.W = torch.zeros((self.np_, self.ldbuf), dtype=torch.float64, device=self.dev)  # one K^-1 column slab
+            self.S = torch.zeros((max(len(self.own), 1) * self.pw, self.ldf), dtype=torch.float64, device=self.dev)
             self.UP = [torch.zeros(self.pw * self.np_, dtype=torch.float64, device=self.dev) for _ in range(2)]
             nsc = self.lib.mi_gp_grad_contract_block_scratch(self.n, 0, self.pw, self.ntheta)
             self.part = torch.zeros(max(int(nsc), 1), dtype=torch.float64, device=self.dev)
@@ -217,16 +218,36 @@ class DistGP:
         nv = max(0, min(self.n - r0, w * 128))  # beta = L^-1 y rides in the first row of the panel's y block
         self.beta_f[r0: r0 + nv].copy_(buf[rows, :nv])
 
-    def _u_rows(self, j):
-        """rows of panel j of U = L^-T, in place in the complete U: X L^T = (rows j of I) over the columns from j on."""
-        w = self._w(j)
-        r0 = j * self.pw
-        blk = self.Uf[r0: r0 + w * 128]
-        blk.zero_()
-        torch.diagonal(blk, offset=r0).fill_(1.0)
-        self._check(self.lib.mi_gp_trsm_block(self.Lf.data_ptr(), self.ldf, self.dinv_f.data_ptr(), j * PW_TILES,
-                                              self.ntc - j * PW_TILES, self._ptr(self.Uf, r0, r0), self.ldf, w * 128,
-                                              self._stream()), "mi_gp_trsm_block")
+    def _u_owned(self):
+        """Rows of U = L^-T for the owned panels, stacked in ascending panel order in self.S: X L^T = (those rows of I).
+        Right-looking over the column panels c: the rows whose panel index is <= c are a prefix of the stack, so every
+        step is one diagonal solve (512 columns) and ONE update GEMM over all active rows -- exact staircase flops
+        (N^3/3 over all ranks) without tall-skinny launches."""
+        S = self.S
+        S.zero_()
+        for li, j in enumerate(self.own):
+            w = self._w(j)
+            torch.diagonal(S[li * self.pw: li * self.pw + w * 128], offset=j * self.pw).fill_(1.0)
+        m = 0
+        nxt = 0
+        for c in range(self.npan):
+            if nxt < len(self.own) and self.own[nxt] == c:
+                m += self._w(c) * 128
+                nxt += 1
+            if m == 0:
+                continue
+            wc, c0 = self._w(c), c * self.pw
+            self._check(self.lib.mi_gp_trsm_block(self.Lf.data_ptr(), self.ldf, self.dinv_f.data_ptr(), c * PW_TILES, wc,
+                                                  self._ptr(S, 0, c0), self.ldf, m, self._stream()), "mi_gp_trsm_block")
+            nrem = self.np_ - c0 - wc * 128
+            if nrem > 0:
+                self._check(self.lib.mi_gp_gemm_f64(0, 1, m, nrem, wc * 128, -1.0, self._ptr(S, 0, c0), self.ldf,
+                                                    self._ptr(self.Lf, c0 + wc * 128, c0), self.ldf, 1.0,
+                                                    self._ptr(S, 0, c0 + wc * 128), self.ldf, 0, 0, 1, 0, 0, 0,
+                                                    self._stream()), "mi_gp_gemm_f64")
+        for li, j in enumerate(self.own):
+            w, r0 = self._w(j), j * self.pw
+            self.Uf[r0: r0 + w * 128, r0: self.np_].copy_(S[li * self.pw: li * self.pw + w * 128, r0: self.np_])
 
     def lml_grad(self, theta):
         """(LML, dLML/dtheta) at natural-scale theta, C-ABI parameter order; (-inf, zeros) if K is not positive definite.
@@ -237,8 +258,7 @@ class DistGP:
             return val, grad
         with torch.cuda.device(self.dev):
             # 1. owned row panels of U
-            for j in self.own:
-                self._u_rows(j)
+            self._u_owned()
             # 2. the exchange: upper part of each row panel, packed, from its owner (two buffers in flight)
             if self.world > 1:
                 pending = []

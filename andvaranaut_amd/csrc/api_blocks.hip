@@ -1,4 +1,5 @@
 // C-ABI building-block entry points (declared in include/mi_gp.h, "block-level operations").
+#include <mutex>
 #include "migp_kernels.h"
 #include "../../include/mi_gp.h"
 
@@ -11,14 +12,19 @@ static int fail(hipError_t e, const char* where) {
 }
 extern "C" const char* mi_gp_last_global_error(void) { return g_err; }
 
-static bool g_lds_enabled = false;
+// kernel attributes (dynamic LDS limits) are per device: set them once for each device a block-level call runs on
+static std::mutex g_init_mutex;
+static unsigned long long g_init_devices = 0;
 static int ensure_init() {
-  if (!g_lds_enabled) {
-    hipError_t e = gemm_f64_enable_lds();
-    if (e == hipSuccess) e = leaf_enable_lds();
-    if (e != hipSuccess) return fail(e, "enable_lds");
-    g_lds_enabled = true;
-  }
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return fail(e, "hipGetDevice");
+  std::lock_guard<std::mutex> lock(g_init_mutex);
+  if (dev < 64 && (g_init_devices >> dev) & 1ull) return 0;
+  e = gemm_f64_enable_lds();
+  if (e == hipSuccess) e = leaf_enable_lds();
+  if (e != hipSuccess) return fail(e, "enable_lds");
+  if (dev < 64) g_init_devices |= 1ull << dev;
   return 0;
 }
 

@@ -75,12 +75,33 @@ static int hfail(mi_gp_handle* h, hipError_t e, const char* where) {
 
 extern "C" const char* mi_gp_last_error(mi_gp_handle* h) { return h ? h->err : "null handle"; }
 
+// frees whatever a (possibly half-built) handle owns; every member is null / empty until it is created
+static void release_handle(mi_gp_handle* h) {
+  (void)hipSetDevice(h->device);
+  if (h->pstream) (void)hipStreamSynchronize(h->pstream);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  (void)hipFree(h->theta_dev); (void)hipFree(h->out_dev); (void)hipFree(h->dinv_dev); (void)hipFree(h->info_dev);
+  (void)hipFree(h->alpha_dev); (void)hipFree(h->part_dev); (void)hipFree(h->gxs_dev); (void)hipFree(h->grad_dev);
+  if (h->grad_host) (void)hipHostFree(h->grad_host);
+  if (h->out_host) (void)hipHostFree(h->out_host);
+  if (h->info_host) (void)hipHostFree(h->info_host);
+  if (h->theta_host) (void)hipHostFree(h->theta_host);
+  for (int i = 0; i < 8; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+  for (auto& ev : h->gemm_ev) (void)hipEventDestroy(ev);
+  for (auto& kv : h->graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);
+  if (h->ev_panel) (void)hipEventDestroy(h->ev_panel);
+  if (h->ev_upd) (void)hipEventDestroy(h->ev_upd);
+  if (h->pstream) (void)hipStreamDestroy(h->pstream);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
 extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   if (!cfg || !out) return -1;
   if (cfg->n <= 0 || cfg->d <= 0 || cfg->nkern <= 0 || cfg->nkern > MAX_KERN) return -1;
   for (int i = 0; i < cfg->nkern; ++i)
     if (cfg->kernel_ids[i] < 0 || cfg->kernel_ids[i] > KID_RATQUAD) return -1;
-  mi_gp_handle* h = new mi_gp_handle();
+  mi_gp_handle* h = new mi_gp_handle();  // value-initialised: every pointer / stream / event starts null
   memset(h->err, 0, sizeof(h->err));
   h->cfg = *cfg;
   h->spec.nkern = cfg->nkern;
@@ -137,9 +158,8 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   if (e == hipSuccess) e = gemm_f64_enable_lds();
   if (e == hipSuccess) e = leaf_enable_lds();
   if (e != hipSuccess) {
-    snprintf(h->err, sizeof(h->err), "mi_gp_create: %s", hipGetErrorString(e));
-    fprintf(stderr, "%s\n", h->err);
-    delete h;
+    fprintf(stderr, "mi_gp_create: %s\n", hipGetErrorString(e));
+    release_handle(h);
     return -2;
   }
   *out = h;
@@ -148,18 +168,7 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
 
 extern "C" int mi_gp_destroy(mi_gp_handle* h) {
   if (!h) return 0;
-  (void)hipSetDevice(h->device);
-  (void)hipStreamSynchronize(h->stream);
-  (void)hipFree(h->theta_dev); (void)hipFree(h->out_dev); (void)hipFree(h->dinv_dev); (void)hipFree(h->info_dev);
-  (void)hipFree(h->alpha_dev); (void)hipFree(h->part_dev); if (h->gxs_dev) (void)hipFree(h->gxs_dev); (void)hipFree(h->grad_dev); (void)hipHostFree(h->grad_host);
-  (void)hipHostFree(h->out_host); (void)hipHostFree(h->info_host); (void)hipHostFree(h->theta_host);
-  for (int i = 0; i < 8; ++i) (void)hipEventDestroy(h->ev[i]);
-  for (auto& ev : h->gemm_ev) (void)hipEventDestroy(ev);
-  for (auto& kv : h->graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);
-  (void)hipEventDestroy(h->ev_panel); (void)hipEventDestroy(h->ev_upd);
-  (void)hipStreamDestroy(h->pstream);
-  (void)hipStreamDestroy(h->stream);
-  delete h;
+  release_handle(h);
   return 0;
 }
 

@@ -197,7 +197,7 @@ class ConsumersMixin:
             xin = np.array([[c for c, _ in cd]])
             dxin = np.array([dv for _, dv in cd])
             # the reference's single-point variance is kstarstar - v^T v, without the noise term (gpmcmc.py:784-785)
-            mu, var, dmu, dvar = self.gp.predict_grad(theta, xin, pred_noise=False, refactor=state["fresh"])
+            mu, var, dmu, dvar = self._ensure_gp().predict_grad(theta, xin, pred_noise=False, refactor=state["fresh"])
             state["fresh"] = False
             m_t = torch.tensor(float(mu[0]), dtype=torch.float64, requires_grad=True)
             v_t = torch.tensor(max(float(var[0]), 1e-300), dtype=torch.float64, requires_grad=True)

@@ -26,6 +26,23 @@ from .priors import HyperModel
 from .transform import _none_conrev, wgp
 
 
+
+def save_object(obj, fname):
+    """core.py:21-23: whole-object checkpoint with cloudpickle (a GPMCMC drops its device handle, see __getstate__)."""
+    import cloudpickle
+
+    with open(fname, "wb") as f:
+        cloudpickle.dump(obj, f)
+
+
+def load_object(fname):
+    """core.py:24-27."""
+    import cloudpickle
+
+    with open(fname, "rb") as f:
+        return cloudpickle.load(f)
+
+
 class GPMCMC(ConsumersMixin):
     def __init__(self, xconrevs=None, yconrevs=None, kernel="RBF", noise=True, mean=0, nx=None, ny=None,
                  priors=None, target=None, parallel=False, nproc=1, constraints=None, rundir=None, verbose=True,
@@ -214,6 +231,20 @@ class GPMCMC(ConsumersMixin):
         if gp is not None:
             gp.close()
         self.gp = None
+
+    # -- checkpoint / resume: the reference pickles the whole object (core.py:21-27 save_object / load_object).  Here
+    # x, y, the conrevs, `m` (the HyperModel) and `hypers` are the state; the device handle is dropped on pickling
+    # and rebuilt from them on the next predict / BO / inverse_opt.
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state["gp"] = None
+        return state
+
+    def _ensure_gp(self):
+        if self.gp is None and self.hypers is not None and self.m is not None:
+            xin, yin = self._converted(self.x, self.y - self.ym)
+            self.gp = MiGP(xin, yin, self.kernel, device=self.device)
+        return self.gp
 
     # ------------------------------------------------------------------ fit
     def fit(self, method="map", return_data=False, iwgp=False, cwgp=False, jitter=1e-6, truncate=False,
@@ -471,7 +502,7 @@ class GPMCMC(ConsumersMixin):
     def predict(self, x, return_var=False, convert=True, revert=True, normvar=False, jitter=1e-6, EI=False,
                 EIopt=None, deg=8):
         """gpmcmc.py:522-542."""
-        if self.gp is None or self.hypers is None:
+        if self._ensure_gp() is None or self.hypers is None:
             raise Exception("Error: fit the GP before predicting")
         if convert:
             xarg = np.zeros_like(x)

@@ -151,3 +151,21 @@ def test_warped_mcmc_short_chain():
     assert data.posterior["cwgp"].shape == (2, 40, 2) and data.posterior["cwgp_pos"].shape == (2, 40, 2)
     assert np.all(np.isfinite(data.sample_stats["lp"]))
     assert np.all(g.hypers["cwgp_pos"] > 0)
+
+
+def test_checkpoint_resume_rebuilds_the_device_handle(tmp_path):
+    """core.py:21-27 pickles the whole object; here the device handle is dropped and rebuilt from x, y, conrevs and hypers."""
+    from andvaranaut_amd import load_object, save_object
+
+    g, fun = _tutorial_gp(kernel="Matern52", noise=True, n=60, seed=5)
+    g.fit(method="map")
+    xt = np.column_stack([np.linspace(0.1, 1.9, 25), np.linspace(1.05, 1.45, 25)])
+    y0, v0 = g.predict(xt, return_var=True)
+    save_object(g, tmp_path / "gp.pickle")
+    g2 = load_object(tmp_path / "gp.pickle")
+    assert g2.gp is None and g2.hypers.keys() == g.hypers.keys()
+    y1, v1 = g2.predict(xt, return_var=True)
+    assert g2.gp is not None
+    assert np.array_equal(y0, y1) and np.array_equal(v0, v1)
+    y2 = g.predict(xt)  # the original keeps working
+    assert np.array_equal(y0, y2)

@@ -59,7 +59,7 @@ class MiGP:
         h = ctypes.c_void_p()
         r = self.lib.mi_gp_create(ctypes.byref(cfg), ctypes.byref(h))
         if r != 0:
-            raise RuntimeError(f"mi_gp_create failed ({r}): {self.lib.mi_gp_last_global_error()}")
+            raise RuntimeError(f"mi_gp_create failed ({r}): {self.lib.mi_gp_last_global_error().decode()}")
         self.h = h
         self.np_ = int(self.lib.mi_gp_padded_n(h))
         self.ntheta = int(self.lib.mi_gp_num_theta(h))

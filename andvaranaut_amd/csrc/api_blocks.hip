@@ -11,6 +11,7 @@ static int fail(hipError_t e, const char* where) {
   return -2;
 }
 extern "C" const char* mi_gp_last_global_error(void) { return g_err; }
+void migp::set_global_error(const char* text) { snprintf(g_err, sizeof(g_err), "%s", text); }
 
 // kernel attributes (dynamic LDS limits) are per device: set them once for each device a block-level call runs on
 static std::mutex g_init_mutex;

@@ -97,10 +97,13 @@ static void release_handle(mi_gp_handle* h) {
 }
 
 extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
-  if (!cfg || !out) return -1;
-  if (cfg->n <= 0 || cfg->d <= 0 || cfg->nkern <= 0 || cfg->nkern > MAX_KERN) return -1;
+  if (!cfg || !out) { set_global_error("mi_gp_create: null argument"); return -1; }
+  if (cfg->n <= 0 || cfg->d <= 0 || cfg->nkern <= 0 || cfg->nkern > MAX_KERN) {
+    set_global_error("mi_gp_create: n, d must be positive and 1 <= nkern <= 4");
+    return -1;
+  }
   for (int i = 0; i < cfg->nkern; ++i)
-    if (cfg->kernel_ids[i] < 0 || cfg->kernel_ids[i] > KID_RATQUAD) return -1;
+    if (cfg->kernel_ids[i] < 0 || cfg->kernel_ids[i] > KID_RATQUAD) { set_global_error("mi_gp_create: unknown kernel id"); return -1; }
   mi_gp_handle* h = new mi_gp_handle();  // value-initialised: every pointer / stream / event starts null
   memset(h->err, 0, sizeof(h->err));
   h->cfg = *cfg;
@@ -158,7 +161,9 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   if (e == hipSuccess) e = gemm_f64_enable_lds();
   if (e == hipSuccess) e = leaf_enable_lds();
   if (e != hipSuccess) {
-    fprintf(stderr, "mi_gp_create: %s\n", hipGetErrorString(e));
+    char msg[200];
+    snprintf(msg, sizeof(msg), "mi_gp_create: %s", hipGetErrorString(e));
+    set_global_error(msg);
     release_handle(h);
     return -2;
   }

@@ -89,4 +89,8 @@ hipError_t launch_predict_grad(const KernSpec& spec, const double* theta, const 
 hipError_t launch_predict_reduce(const double* A, long lda, const double* beta, int n, int m, double kdiag,
                                  double noise, double* mean, double* var, hipStream_t stream);
 
+// ---------------------------------------------------------------- api_blocks.hip
+// text behind mi_gp_last_global_error() (calls that have no handle to carry it: mi_gp_create, the block-level entries)
+void set_global_error(const char* text);
+
 }  // namespace migp

@@ -35,6 +35,13 @@ def test_bad_arguments_are_reported_not_crashed():
     cfg.n, cfg.d, cfg.nkern = 0, 1, 1
     h = ctypes.c_void_p()
     assert lib.mi_gp_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
+    assert b"mi_gp_create" in lib.mi_gp_last_global_error()
+    # the sharded-gradient blocks validate before touching the device too
+    assert lib.mi_gp_trsm_block(None, 16, None, 0, 1, None, 16, 128, None) == -1
+    assert lib.mi_gp_trmv_upper(None, 16, None, 4, None, None) == -1
+    assert lib.mi_gp_grad_contract_block_scratch(1000, 512, 512, 10) == (16 - 8) * 8 * 10  # 16 tile rows, slab = columns 8..15
+    ids = (ctypes.c_int * 4)(0, 0, 0, 0)
+    assert lib.mi_gp_grad_contract_block(2, 1, ids, ids, None, None, 100, None, 16, 64, 0, 64, None, None, 0, None, None) == -1
 
 
 def test_product_package_never_imports_the_oracle():

@@ -42,6 +42,8 @@ struct mi_gp_handle {
   double* grad_dev;     // [ntheta]
   double* grad_host;    // pinned [ntheta]
   int* info_dev;
+  int* ready_dev;       // [ntc] leaf -> strip words of the fused launches, zeroed before every evaluation
+  int fuse_thr;         // leaf + strip in ONE launch for tile columns with at most this many columns after them (option 13)
   double* out_host;     // pinned [16]
   int* info_host;       // pinned
   double* theta_host;   // pinned
@@ -81,6 +83,7 @@ static void release_handle(mi_gp_handle* h) {
   if (h->pstream) (void)hipStreamSynchronize(h->pstream);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   (void)hipFree(h->theta_dev); (void)hipFree(h->out_dev); (void)hipFree(h->dinv_dev); (void)hipFree(h->info_dev);
+  (void)hipFree(h->ready_dev);
   (void)hipFree(h->alpha_dev); (void)hipFree(h->part_dev); (void)hipFree(h->gxs_dev); (void)hipFree(h->grad_dev);
   if (h->grad_host) (void)hipHostFree(h->grad_host);
   if (h->out_host) (void)hipHostFree(h->out_host);
@@ -154,6 +157,8 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   if (e == hipSuccess) e = hipMalloc(&h->grad_dev, sizeof(double) * h->ntheta);
   if (e == hipSuccess) e = hipHostMalloc(&h->grad_host, sizeof(double) * h->ntheta);
   if (e == hipSuccess) e = hipMalloc(&h->info_dev, sizeof(int) * 4);
+  if (e == hipSuccess) e = hipMalloc(&h->ready_dev, sizeof(int) * (size_t)h->ntc);
+  h->fuse_thr = 64;
   if (e == hipSuccess) e = hipHostMalloc(&h->out_host, sizeof(double) * 16);
   if (e == hipSuccess) e = hipHostMalloc(&h->info_host, sizeof(int) * 4);
   if (e == hipSuccess) e = hipHostMalloc(&h->theta_host, sizeof(double) * h->ntheta);
@@ -213,6 +218,7 @@ extern "C" int mi_gp_set_option(mi_gp_handle* h, int what, int value) {
   else if (what == 10) h->bulk_wide_late = value;
   else if (what == 12) { set_leaf_exclusive(value); for (auto& kv : h->graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second); h->graphs.clear(); }
   else if (what == 11) h->bulk_wide_thr = value;
+  else if (what == 13) h->fuse_thr = value;
   else return -1;
   return 0;
 }
@@ -281,9 +287,14 @@ static hipError_t chol_panel(mi_gp_handle* h, double* A, long lda, int ntr, int 
   if (w == 1) {
     double* blk = A + (long)c0 * 128 * lda + (long)c0 * 128;
     double* dinv = h->dinv_dev + (size_t)c0 * 2048;
+    const int m = (ntr - c0 - 1) * 128;
+    // Fused launch where the panel chain is the critical path (saves the launch boundary and lets the strip's rows
+    // travel during the leaf: -4 % at N <= 8192).  While the bulk update is the long pole the waiting strip workgroups
+    // would only take CU slots from it (+2 % at N = 16384 when fused everywhere).
+    if (ntr - 1 - c0 <= h->fuse_thr)
+      return launch_potrf_leaf_strip128(blk, lda, dinv, c0 * 128, h->info_dev, blk + 128 * lda, lda, m, h->ready_dev + c0, st);
     e = launch_potrf_leaf128(blk, lda, dinv, c0 * 128, h->info_dev, st);
     if (e != hipSuccess) return e;
-    const int m = (ntr - c0 - 1) * 128;
     return launch_trsm_strip128(blk, lda, dinv, blk + 128 * lda, lda, m, st);
   }
   const int w1 = w / 2, w2 = w - w1;
@@ -380,13 +391,14 @@ static int run_evaluation(mi_gp_handle* h, int what) {
   h->gemm_flops_acc = 0.0;
   HCK(hipMemcpyAsync(h->theta_dev, h->theta_host, sizeof(double) * h->ntheta, hipMemcpyHostToDevice, h->stream), "theta upload");
   HCK(hipMemsetAsync(h->info_dev, 0x7f, sizeof(int) * 4, h->stream), "info reset");
+  HCK(hipMemsetAsync(h->ready_dev, 0, sizeof(int) * (size_t)h->ntc, h->stream), "ready reset");
   if (prof || !h->use_graph) {
     if (int r = enqueue_factor(h, noise_form, prof)) return r;
     if (what == 2) { if (int r = enqueue_gradient(h, prof)) return r; }
     return download_results(h, what);
   }
   const int key = what | (h->lookahead << 4) | ((h->bulk_wide ? 1 : 0) << 5) | ((h->cfg.panel_tiles & 0xff) << 8) | (gemm_variant_get() << 20) |
-                  ((h->w_thr[0] * 31 + h->w_thr[1] * 7 + h->w_thr[2] + h->lowocc_thr * 13 + h->bulk_wide * 3 + h->bulk_wide_late * 5 + h->bulk_wide_thr * 11) & 0x7ff) << 21;
+                  ((h->w_thr[0] * 31 + h->w_thr[1] * 7 + h->w_thr[2] + h->lowocc_thr * 13 + h->bulk_wide * 3 + h->bulk_wide_late * 5 + h->bulk_wide_thr * 11 + h->fuse_thr * 17) & 0x7ff) << 21;
   auto it = h->graphs.find(key);
   if (it == h->graphs.end()) {
     // First use: time one evaluation with plain launches, then capture + instantiate and time a
@@ -415,6 +427,7 @@ static int run_evaluation(mi_gp_handle* h, int what) {
       if (e != hipSuccess) return hfail(h, e, "graph instantiate");
       float t_graph = 0.f;
       HCK(hipMemsetAsync(h->info_dev, 0x7f, sizeof(int) * 4, h->stream), "info reset");
+      HCK(hipMemsetAsync(h->ready_dev, 0, sizeof(int) * (size_t)h->ntc, h->stream), "ready reset");
       (void)hipEventRecord(h->ev[0], h->stream);
       HCK(hipGraphLaunch(exec, h->stream), "graph launch");
       (void)hipEventRecord(h->ev[1], h->stream);

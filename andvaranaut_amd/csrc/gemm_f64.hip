@@ -906,7 +906,7 @@ static int gemm_variant() {
 }
 
 static int g_small_tiles = 1024;
-constexpr size_t LDS_ONE_PER_CU = 84 * 1024;
+constexpr size_t LDS_ONE_PER_CU = 82432;  // > half a CU (one workgroup per CU) and <= 160 KB - the 79 KB leaf image
 constexpr size_t LDS_WHOLE_CU = 160 * 1024;  // 160 KB per CU: two of these do not fit, one + a 76 KB leaf does
 void set_gemm_variant(int v) { g_variant = v; }
 void set_gemm_small_tiles(int v) { g_small_tiles = v; }

@@ -180,10 +180,8 @@ struct ScaleCols<16> {
 //      is ONE instruction and there is no LDS round trip per pivot;
 //  (B) rows below: X = B L16^-T, one thread per row, column-oriented substitution in registers;
 //  (C) trailing update of the remaining lower tiles on fp64 MFMA (rank 16).
-__global__ __launch_bounds__(256, 1) void potrf_leaf128_kernel(double* __restrict__ Ablk, long lda,
-                                                                double* __restrict__ dinv, int col0,
-                                                                int* __restrict__ info) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
+__device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, long lda, double* __restrict__ dinv,
+                                                    int col0, int* __restrict__ info, double* smem) {
   double* S = smem;                     // packed lower block-trapezoid, see soff()
   double* LdT2 = smem + LEAF_ELEMS;     // [2][16][16]  LdT[k][c] = L16[c][k] of diagonal sub-block jb (buffer jb & 1)
   double* invd = LdT2 + 2 * SB * SB;    // [128] 1 / L[c][c]
@@ -401,6 +399,13 @@ __global__ __launch_bounds__(256, 1) void potrf_leaf128_kernel(double* __restric
   LEAF_STAMP(5);
 }
 
+__global__ __launch_bounds__(256, 1) void potrf_leaf128_kernel(double* __restrict__ Ablk, long lda,
+                                                                double* __restrict__ dinv, int col0,
+                                                                int* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  potrf_leaf128_body(Ablk, lda, dinv, col0, info, smem);
+}
+
 // X * L^T = B, in place on B (m x 128, leading dimension ldb, m multiple of 64).
 // One wave per 16 rows; tiles kept transposed: T_j[r] = B[row0 + (l&15)][16j + 4r + (l>>4)].
 // The 28 sub-diagonal 16x16 tiles of L and the 8 inverse diagonal blocks are staged once per
@@ -410,16 +415,13 @@ __global__ __launch_bounds__(256, 1) void potrf_leaf128_kernel(double* __restric
 constexpr int STRIP_TILES = 36;  // 28 sub-diagonal tiles of L + 8 diagonal inverses
 __device__ __forceinline__ int strip_tile(int i, int j) { return i * (i - 1) / 2 + j; }  // i > j
 
-__global__ __launch_bounds__(256) void trsm_strip128_kernel(const double* __restrict__ Lblk, long lda,
-                                                             const double* __restrict__ dinv,
-                                                             double* __restrict__ B, long ldb, long strideL,
-                                                             long strideB) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
+// `ready` (fused leaf + strip launch only): word the leaf workgroup of the same launch sets once L and dinv are in
+// memory; the right-hand side rows are loaded first, so they travel while the leaf is still factoring.
+__device__ __forceinline__ void trsm_strip128_body(const double* __restrict__ Lblk, long lda,
+                                                    const double* __restrict__ dinv, double* __restrict__ B, long ldb,
+                                                    int blk, double* smem, int* ready, int* __restrict__ info) {
   double* Lt = smem;             // [28][4][64]
   double* Dt = smem + 28 * 256;  // [8][4][64]
-  Lblk += (long)blockIdx.y * strideL;
-  dinv += (long)blockIdx.y * 2048;
-  B += (long)blockIdx.y * strideB;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -428,12 +430,26 @@ __global__ __launch_bounds__(256) void trsm_strip128_kernel(const double* __rest
   unsigned long long t_prev = 0;
   if (threadIdx.x == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory");
 #endif
-  double* Brow = B + ((long)blockIdx.x * 64 + wave * 16 + n) * ldb;
+  double* Brow = B + ((long)blk * 64 + wave * 16 + n) * ldb;
   double4_t T[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j)
 #pragma unroll
     for (int r = 0; r < 4; ++r) T[j][r] = Brow[16 * j + 4 * r + q];
+  if (ready) {
+    if (tid == 0) {
+      // bounded wait (about a second of the 100 MHz wall clock): a lost leaf must not hang the device
+      const unsigned long long t0 = wall_clock64();
+      bool ok = true;
+      while (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+        __builtin_amdgcn_s_sleep(1);
+        if (wall_clock64() - t0 > 100000000ull) { ok = false; break; }
+      }
+      if (!ok) atomicMin(info, -3);
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
   // stage L tiles: item = (tile, row, column quad) -> 4 doubles
   {
     typedef double double2_t __attribute__((ext_vector_type(2)));
@@ -467,7 +483,7 @@ __global__ __launch_bounds__(256) void trsm_strip128_kernel(const double* __rest
   }
   __syncthreads();
 #ifdef LEAF_STAMPS
-  if (blockIdx.x == 0) LEAF_STAMP(6);
+  if (blk == 0) LEAF_STAMP(6);
 #endif
   double4_t La[2][7];  // double buffer over block columns j: La[j&1][i-j-1][s]
   double4_t Dj[2];
@@ -498,12 +514,37 @@ __global__ __launch_bounds__(256) void trsm_strip128_kernel(const double* __rest
         T[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(La[cur][i - j - 1][s4], Xn[s4], T[i], 0, 0, 0);
   }
 #ifdef LEAF_STAMPS
-  if (blockIdx.x == 0) LEAF_STAMP(7);
+  if (blk == 0) LEAF_STAMP(7);
 #endif
 #pragma unroll
   for (int j = 0; j < 8; ++j)
 #pragma unroll
     for (int r = 0; r < 4; ++r) Brow[16 * j + 4 * r + q] = T[j][r];
+}
+
+__global__ __launch_bounds__(256) void trsm_strip128_kernel(const double* __restrict__ Lblk, long lda,
+                                                             const double* __restrict__ dinv,
+                                                             double* __restrict__ B, long ldb, long strideL,
+                                                             long strideB) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  trsm_strip128_body(Lblk + (long)blockIdx.y * strideL, lda, dinv + (long)blockIdx.y * 2048, B + (long)blockIdx.y * strideB,
+                     ldb, blockIdx.x, smem, nullptr, nullptr);
+}
+
+// Leaf and the strip below it in ONE launch: workgroup 0 factors the diagonal block and raises `ready`; the other
+// workgroups have their rows in registers by then and start the solve without a launch boundary in between.
+__global__ __launch_bounds__(256, 1) void potrf_leaf_strip128_kernel(double* __restrict__ Ablk, long lda,
+                                                                      double* __restrict__ dinv, int col0,
+                                                                      int* __restrict__ info, double* __restrict__ B,
+                                                                      long ldb, int* __restrict__ ready) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  if (blockIdx.x == 0) {
+    potrf_leaf128_body(Ablk, lda, dinv, col0, info, smem);
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(ready, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    trsm_strip128_body(Ablk, lda, dinv, B, ldb, blockIdx.x - 1, smem, ready, info);
+  }
 }
 
 constexpr size_t LEAF_LDS_BYTES = sizeof(double) * (LEAF_ELEMS + 2 * SB * SB + LEAF + 2);
@@ -519,12 +560,23 @@ hipError_t leaf_enable_lds() {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_leaf128_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAF_LDS_WHOLE_CU);
   if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_leaf_strip128_kernel),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAF_LDS_WHOLE_CU);
+  if (e != hipSuccess) return e;
   return hipFuncSetAttribute(reinterpret_cast<const void*>(trsm_strip128_kernel),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)STRIP_LDS_BYTES);
 }
 
 hipError_t launch_potrf_leaf128(double* Ablk, long lda, double* dinv, int col0, int* info, hipStream_t stream) {
   potrf_leaf128_kernel<<<1, 256, g_leaf_exclusive ? LEAF_LDS_WHOLE_CU : LEAF_LDS_BYTES, stream>>>(Ablk, lda, dinv, col0, info);
+  return hipGetLastError();
+}
+
+hipError_t launch_potrf_leaf_strip128(double* Ablk, long lda, double* dinv, int col0, int* info, double* B, long ldb, int m,
+                                      int* ready, hipStream_t stream) {
+  if (m <= 0) return launch_potrf_leaf128(Ablk, lda, dinv, col0, info, stream);
+  const size_t lds = g_leaf_exclusive ? LEAF_LDS_WHOLE_CU : (LEAF_LDS_BYTES > STRIP_LDS_BYTES ? LEAF_LDS_BYTES : STRIP_LDS_BYTES);
+  potrf_leaf_strip128_kernel<<<1 + m / 64, 256, lds, stream>>>(Ablk, lda, dinv, col0, info, B, ldb, ready);
   return hipGetLastError();
 }
 

@@ -38,6 +38,9 @@ void set_leaf_exclusive(int on);
 // in-place lower Cholesky of one 128x128 diagonal block; dinv receives the inverses of its eight
 // 16x16 diagonal sub-blocks ([8][16][16]); *info gets atomicMin(col0 + j + 1) on a bad pivot.
 hipError_t launch_potrf_leaf128(double* Ablk, long lda, double* dinv, int col0, int* info, hipStream_t stream);
+// leaf and the strip below it (m rows at B) in one launch; *ready must be 0 on entry (one word per launch)
+hipError_t launch_potrf_leaf_strip128(double* Ablk, long lda, double* dinv, int col0, int* info, double* B, long ldb, int m,
+                                      int* ready, hipStream_t stream);
 // X * L^T = B in place on the m x 128 panel B (m multiple of 64).
 hipError_t launch_trsm_strip128(const double* Lblk, long lda, const double* dinv, double* B, long ldb, int m,
                                 hipStream_t stream);

@@ -118,7 +118,8 @@ int mi_gp_predict_grad(mi_gp_handle* h, const double* Xnew_dev, int m, double* w
  * 7 launches with fewer 128x128 tiles than this run on 64x64 tiles (process-wide, default 1024); 8 trailing size at or below which look-ahead bulk updates run one workgroup
  * per CU (default 64); 9 look-ahead bulk kernel: 0 = 4-wave kernel (default), 1 = 8-wave / one workgroup per CU,
  * n > 1 = the same persistent on n CUs taken whole (n | 0x1000: half-CU LDS request, the others stay shareable);
- * 10, 11 = the option-9 value used once <= (11) tile columns remain; 12 = the leaf kernel asks for a whole CU. */
+ * 10, 11 = the option-9 value used once <= (11) tile columns remain; 12 = the leaf kernel asks for a whole CU;
+ * 13 = tile columns with at most this many columns after them run leaf + strip as ONE launch (default 64, 0 = never). */
 int mi_gp_set_option(mi_gp_handle* h, int what, int value);
 
 /* profiling: level 0 none, 1 per-phase HIP events, 2 additionally per-GEMM-launch HIP events */

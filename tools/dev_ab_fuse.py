@@ -1,4 +1,4 @@
-"""A/B: leaf + strip in one launch for the last `fuse` tile columns (mi_gp_set_option 13; 0 = never) against separate launches."""
+"""A/B: leaf + strip in one launch  for the last `fuse` tile columns (mi_gp_set_option 13; 0 = never) against separate launches."""
 import sys
 import time
 
@@ -13,7 +13,7 @@ for N in sizes:
     th = theta_sequence(d, 14, seed=0)
     gp = MiGP(X, y, kern, need_grad=False)
     ref = None
-    for fuse in (0, 64, 0, 64, 96, 1 << 20):
+    for fuse in (0, 64, 0, 64):
         gp.set_option(13, fuse)
         for i in range(3):
             gp.lml(th[i])

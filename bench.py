@@ -102,7 +102,7 @@ def cpu_baseline(N, d, kernel, budget_s=25.0):
 
 
 def sharded_main(args, X, y, rank, world, dev):
-    """Strong-scaling variant: every rank owns a block-cyclic share of the 512-column panels of ONE
+    """Strong-scaling variant: every rank owns a block-cyclic share of the 512/1024-column panels of ONE
     covariance (andvaranaut_amd/distributed.py); one broadcast per panel over RCCL."""
     import torch
     import torch.distributed as dist
@@ -136,7 +136,7 @@ def sharded_main(args, X, y, rank, world, dev):
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.kernel} GP LML eval, ONE covariance N={N} d={d} sharded over {world} GPU(s)",
-                       "N": N, "d": d, "kernel": args.kernel, "parallelism": f"column-panel block-cyclic x{world}"},
+                       "N": N, "d": d, "kernel": args.kernel, "parallelism": f"column-panel ({gp.pw} columns) block-cyclic x{world}"},
             "cholesky_tflops_whole_eval": (N ** 3 / 3.0) / (elapsed / args.steps) * 1e-12}), flush=True)
     if world > 1:
         dist.destroy_process_group()

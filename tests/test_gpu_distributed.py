@@ -33,6 +33,27 @@ def test_single_rank_matches_oracle(N, d, kernel):
     assert abs(gp.lml(theta) - ref) <= 1e-10 * abs(ref)
 
 
+def test_single_rank_wide_panels_match_single_gpu_path():
+    """N large enough for the 1024-column panels the driver picks on its own (ragged last panel of one tile)."""
+    from andvaranaut_amd import MiGP
+    from andvaranaut_amd.distributed import DistGP, panel_tiles
+    from oracle import gp_oracle as orc
+
+    N, d = 4200, 4
+    assert panel_tiles((N + 127) // 128, 1) == 8 and panel_tiles(24, 2) == 4
+    X, y = orc.synth_problem(N, d, seed=3)
+    theta = orc.synth_theta(d, nkern=1)
+    gp = DistGP(X, y, "Matern52")
+    assert gp.pwt == 8 and gp.npan == 5 and gp._w(4) == 1
+    val, g = gp.lml_grad(theta)
+    one = MiGP(X, y, "Matern52")
+    v1, g1 = one.lml_grad(theta)
+    assert abs(val - v1) <= 1e-11 * abs(v1)
+    assert _grad_close(g, g1, rtol=1e-8), (g, g1)
+    assert abs(gp.lml(theta) - orc.lml(X, y, ["Matern52"], [], theta)) <= 1e-10 * abs(v1)
+    one.close()
+
+
 def _grad_close(g, ref, rtol=1e-7):
     scale = np.maximum(np.abs(ref), 1e-3 * np.max(np.abs(ref)))
     return np.max(np.abs(g - ref) / scale) <= rtol
@@ -80,12 +101,13 @@ from oracle import gp_oracle as orc
 rank, world, _ = parallel.init_distributed(backend="gloo")
 torch.cuda.set_device(0)
 out = {}
-for (N, d, kernel) in [(1500, 4, "RBF"), (2100, 5, "Matern52"), (3000, 3, "RBF+Matern32")]:
+for (N, d, kernel, pwt) in [(1500, 4, "RBF", None), (2100, 5, "Matern52", None), (3000, 3, "RBF+Matern32", None),
+                            (2900, 3, "Matern52", 8)]:
     X, y = orc.synth_problem(N, d, seed=N)
     kerns, ops = kernel.split("+"), ["+"] * (kernel.count("+"))
     theta = orc.synth_theta(d, nkern=len(kerns))
-    gp = DistGP(X, y, kernel, device=0)
-    assert len(gp.own) >= 1 and gp.npan >= 3
+    gp = DistGP(X, y, kernel, device=0, panel_width_tiles=pwt)
+    assert gp.npan >= 3 and (len(gp.own) >= 1 or pwt)
     val = gp.lml(theta)
     ref = orc.lml(X, y, kerns, ops, theta)
     assert abs(val - ref) <= 1e-10 * abs(ref), (rank, N, val, ref)
@@ -93,7 +115,7 @@ for (N, d, kernel) in [(1500, 4, "RBF"), (2100, 5, "Matern52"), (3000, 3, "RBF+M
     _, gref = orc.lml_grad(X, y, kerns, ops, theta)
     scale = np.maximum(np.abs(gref), 1e-3 * np.max(np.abs(gref)))
     assert v2 == val and np.max(np.abs(g - gref) / scale) <= 1e-7, (rank, N, g, gref)
-    out[N] = [val] + g.tolist()
+    out[(N, pwt)] = [val] + g.tolist()
 vals = parallel.gather_objects(out)
 assert all(v == vals[0] for v in vals), vals  # every rank holds the same all-reduced LML
 if rank == 0:

@@ -505,6 +505,10 @@ static int factor_internal(mi_gp_handle* h, const double* theta, int what) {
     }
   }
   const int info = h->info_host[0];
+  if (info < 0) {  // only the bounded wait of a fused leaf + strip launch writes a negative value
+    snprintf(h->err, sizeof(h->err), "a strip workgroup gave up waiting for its leaf (fused launch, code %d)", info);
+    return -2;
+  }
   if (info != 0x7f7f7f7f) return info;  // 1-based index of the first bad pivot
   return 0;
 }

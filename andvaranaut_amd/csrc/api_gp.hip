@@ -213,6 +213,11 @@ extern "C" int mi_gp_set_option(mi_gp_handle* h, int what, int value) {
     for (auto& kv : h->graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);  // captured launches used the old routing
     h->graphs.clear();
   }
+  else if (what == 14) {
+    set_gemm_band_rows(value);
+    for (auto& kv : h->graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);  // captured launches used the old order
+    h->graphs.clear();
+  }
   else if (what == 8) h->lowocc_thr = value;
   else if (what == 9) h->bulk_wide = value;
   else if (what == 10) h->bulk_wide_late = value;

@@ -96,6 +96,29 @@ __device__ __forceinline__ void tile_from_index(const GemmParams& p, int idx, in
   }
 }
 
+// Band-column-major enumeration of the lower trapezoid: bands of R tile rows; inside a band the columns left to right,
+// inside a column the band's rows top to bottom.  The 64 tiles an XCD works on at a time then cover ~R row strips and
+// ~64/R column strips (each fetched into that L2 once and hit by the others) instead of one row strip and 64 column strips.
+__device__ __forceinline__ void tile_from_index_banded(const GemmParams& p, int idx, int R, int& ti, int& tj) {
+  auto before = [&](int r) { return r <= p.nt ? r * (r + 1) / 2 : p.nt * (p.nt + 1) / 2 + (r - p.nt) * p.nt; };
+  int lo = 0, hi = (p.mt + R - 1) / R - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (before(mid * R) <= idx) lo = mid; else hi = mid - 1;
+  }
+  const int r0 = lo * R, r1 = min(r0 + R, p.mt), h = r1 - r0;
+  int e = idx - before(r0);
+  const int cfull = min(r0 + 1, p.nt);  // columns that hold all h rows of the band
+  if (e < cfull * h) { tj = e / h; ti = r0 + e % h; return; }
+  e -= cfull * h;
+  for (tj = cfull; tj < p.nt; ++tj) {    // the band's own triangle: column tj holds rows tj .. r1-1
+    const int cnt = r1 - tj;
+    if (e < cnt) { ti = tj + e; return; }
+    e -= cnt;
+  }
+  ti = r1 - 1; tj = min(ti, p.nt - 1);
+}
+
 template <bool A_KMAJOR, bool B_KMAJOR>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -303,7 +326,8 @@ __global__ __launch_bounds__(vb::NT_B, 2) void gemm_f64_kernel_b(GemmParams p) {
     idx = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
   }
   int ti, tj;
-  tile_from_index(p, idx, ti, tj);
+  if (p.band > 0 && p.tri && p.kmode == 0) tile_from_index_banded(p, idx, p.band, ti, tj);
+  else tile_from_index(p, idx, ti, tj);
   if (p.kmode == 2) ti = p.mt - 1 - ti;
   if (p.kmode == 4 && !p.tri) { tj = p.nt - 1 - idx / p.mt; ti = idx % p.mt; }  // longest-k columns first (LPT order)
   const int i0 = ti * TILE, j0 = tj * TILE;
@@ -906,6 +930,8 @@ static int gemm_variant() {
 }
 
 static int g_small_tiles = 1024;
+static int g_band_rows = 8;  // > 0: band-column-major tile order for the uniform-k trapezoid launches of the 128-tile kernel
+void set_gemm_band_rows(int v) { g_band_rows = v; }
 constexpr size_t LDS_ONE_PER_CU = 82432;  // > half a CU (one workgroup per CU) and <= 160 KB - the 79 KB leaf image
 constexpr size_t LDS_WHOLE_CU = 160 * 1024;  // 160 KB per CU: two of these do not fit, one + a 76 KB leaf does
 void set_gemm_variant(int v) { g_variant = v; }
@@ -955,6 +981,9 @@ hipError_t launch_gemm_f64(const GemmParams& p, int opA_kmajor, int opB_kmajor, 
   if (gemm_variant() == 1) {
     dim3 grid(nblk, 1, batch), block(vb::NT_B);
     const size_t lds = p.one_per_cu ? LDS_ONE_PER_CU : sizeof(double) * 4 * vb::OPER_B;
+    GemmParams pb = p;
+    pb.band = g_band_rows;
+    const GemmParams& p = pb;
     if (!opA_kmajor && !opB_kmajor) gemm_f64_kernel_b<false, false><<<grid, block, lds, stream>>>(p);
     else if (!opA_kmajor && opB_kmajor) gemm_f64_kernel_b<false, true><<<grid, block, lds, stream>>>(p);
     else if (opA_kmajor && opB_kmajor) gemm_f64_kernel_b<true, true><<<grid, block, lds, stream>>>(p);

@@ -20,6 +20,7 @@ struct GemmParams {
   int ntiles = 0;                   // variant C persistent form: total tiles when the grid is smaller (set by the launcher)
   int wide8 = 0;                    // launcher only: 1 = 8-wave / one-workgroup-per-CU kernel (variant C) that leaves half of
                                     // every CU's LDS and registers to the panel chain
+  int band = 0;                     // launcher only: band height (tile rows) of the band-column-major trapezoid order, 0 = row-major
   int one_per_cu = 0;               // launcher only: request > half a CU's LDS so that one workgroup per CU runs (leaves room for
                                     // the panel chain's leaf / strip kernels next to a bulk update)
 };
@@ -30,6 +31,7 @@ hipError_t gemm_f64_enable_lds();
 int gemm_variant_get();
 void set_gemm_variant(int v);
 void set_gemm_small_tiles(int v);
+void set_gemm_band_rows(int v);
 bool gemm_uses_small_tiles(const GemmParams& p, int batch);  // true: the 64x64-tile kernel will run  // launches with fewer 128x128 tiles than this use 64x64 tiles  // 0: 8-wave / 1 workgroup per CU, 1: 4-wave / 2 workgroups per CU (default)
 
 // ---------------------------------------------------------------- leaf_f64.hip

@@ -119,7 +119,9 @@ int mi_gp_predict_grad(mi_gp_handle* h, const double* Xnew_dev, int m, double* w
  * per CU (default 64); 9 look-ahead bulk kernel: 0 = 4-wave kernel (default), 1 = 8-wave / one workgroup per CU,
  * n > 1 = the same persistent on n CUs taken whole (n | 0x1000: half-CU LDS request, the others stay shareable);
  * 10, 11 = the option-9 value used once <= (11) tile columns remain; 12 = the leaf kernel asks for a whole CU;
- * 13 = tile columns with at most this many columns after them run leaf + strip as ONE launch (default 64, 0 = never). */
+ * 13 = tile columns with at most this many columns after them run leaf + strip as ONE launch (default 64, 0 = never);
+ * 14 = band height (tile rows) of the band-column-major tile order of uniform-k trapezoid launches (process-wide,
+ * default 8, 0 = row-major). */
 int mi_gp_set_option(mi_gp_handle* h, int what, int value);
 
 /* profiling: level 0 none, 1 per-phase HIP events, 2 additionally per-GEMM-launch HIP events */

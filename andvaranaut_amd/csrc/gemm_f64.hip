@@ -96,11 +96,14 @@ __device__ __forceinline__ void tile_from_index(const GemmParams& p, int idx, in
   }
 }
 
-// Band-column-major enumeration of the lower trapezoid: bands of R tile rows; inside a band the columns left to right,
+// Band-column-major enumeration of the lower trapezoid (tri) or the full rectangle: bands of R tile rows; inside a band the columns left to right,
 // inside a column the band's rows top to bottom.  The 64 tiles an XCD works on at a time then cover ~R row strips and
 // ~64/R column strips (each fetched into that L2 once and hit by the others) instead of one row strip and 64 column strips.
 __device__ __forceinline__ void tile_from_index_banded(const GemmParams& p, int idx, int R, int& ti, int& tj) {
-  auto before = [&](int r) { return r <= p.nt ? r * (r + 1) / 2 : p.nt * (p.nt + 1) / 2 + (r - p.nt) * p.nt; };
+  auto before = [&](int r) {  // tiles in tile rows [0, r)
+    if (!p.tri) return r * p.nt;
+    return r <= p.nt ? r * (r + 1) / 2 : p.nt * (p.nt + 1) / 2 + (r - p.nt) * p.nt;
+  };
   int lo = 0, hi = (p.mt + R - 1) / R - 1;
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
@@ -108,7 +111,7 @@ __device__ __forceinline__ void tile_from_index_banded(const GemmParams& p, int 
   }
   const int r0 = lo * R, r1 = min(r0 + R, p.mt), h = r1 - r0;
   int e = idx - before(r0);
-  const int cfull = min(r0 + 1, p.nt);  // columns that hold all h rows of the band
+  const int cfull = p.tri ? min(r0 + 1, p.nt) : p.nt;  // columns that hold all h rows of the band
   if (e < cfull * h) { tj = e / h; ti = r0 + e % h; return; }
   e -= cfull * h;
   for (tj = cfull; tj < p.nt; ++tj) {    // the band's own triangle: column tj holds rows tj .. r1-1
@@ -326,6 +329,7 @@ __global__ __launch_bounds__(vb::NT_B, 2) void gemm_f64_kernel_b(GemmParams p) {
     idx = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
   }
   int ti, tj;
+  // (full rectangles measured neutral: 8192^3 75.2 vs 75.7 TFLOP/s -- the row-major order stays for them)
   if (p.band > 0 && p.tri && p.kmode == 0) tile_from_index_banded(p, idx, p.band, ti, tj);
   else tile_from_index(p, idx, ti, tj);
   if (p.kmode == 2) ti = p.mt - 1 - ti;

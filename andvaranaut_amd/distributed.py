@@ -49,6 +49,10 @@ class DistGP:
         self.lib = _lib.load()
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        # With a process group the exchange steps are always issued (a one-rank group included: the RCCL call path is
+        # then the one a multi-GPU run takes); without one there is nothing to exchange.
+        self.collective = dist.is_initialized()
+        self.bytes_broadcast = 0
         X = np.ascontiguousarray(X, dtype=np.float64)
         y = np.ascontiguousarray(np.asarray(y, dtype=np.float64).reshape(-1))
         self.n, self.d = X.shape
@@ -180,7 +184,7 @@ class DistGP:
                                                        self._stream()), "mi_gp_lml_partial")
                 acc[:2] += self.out[1:3]
             info = self.info[:1].clone()
-            if self.world > 1:
+            if self.collective:
                 dist.all_reduce(acc, op=dist.ReduceOp.SUM)
                 dist.all_reduce(info, op=dist.ReduceOp.MIN)
             logdet, quad = acc[0].item(), acc[1].item()
@@ -191,10 +195,11 @@ class DistGP:
         return -0.5 * self.n * math.log(2.0 * math.pi) - 0.5 * quad - logdet
 
     def _bcast(self, j):
-        if self.world == 1:
+        if not self.collective:
             return None
         rows = self.np_ + 128 - j * self.pw + DINV_ROWS
         view = self.P[j % 2][:rows]  # contiguous leading rows of the panel buffer
+        self.bytes_broadcast += view.numel() * 8
         return dist.broadcast(view, src=j % self.world, async_op=True)
 
     # ------------------------------------------------------------------ gradient
@@ -267,7 +272,7 @@ class DistGP:
             # 1. owned row panels of U
             self._u_owned()
             # 2. the exchange: upper part of each row panel, packed, from its owner (two buffers in flight)
-            if self.world > 1:
+            if self.collective:
                 pending = []
                 for j in range(self.npan):
                     w, r0 = self._w(j), j * self.pw
@@ -277,6 +282,7 @@ class DistGP:
                         self._finish_u(*pending.pop(0))
                     if j % self.world == self.rank:
                         pk.copy_(self.Uf[r0: r0 + w * 128, r0: self.np_])
+                    self.bytes_broadcast += pk.numel() * 8
                     pending.append((j, pk, dist.broadcast(pk, src=j % self.world, async_op=True)))
                 while pending:
                     self._finish_u(*pending.pop(0))
@@ -299,7 +305,7 @@ class DistGP:
                     self.part.numel(), self.gslab.data_ptr(), self._stream()), "mi_gp_grad_contract_block")
                 gsum += self.gslab
             # 4. one small all-reduce
-            if self.world > 1:
+            if self.collective:
                 dist.all_reduce(gsum, op=dist.ReduceOp.SUM)
             grad = gsum.cpu().numpy()
         return val, grad

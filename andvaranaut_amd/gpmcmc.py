@@ -62,6 +62,9 @@ class GPMCMC(ConsumersMixin):
             raise Exception("Error: parallel must be type bool.")
         if parallel:
             raise NotImplementedError("dask-parallel target evaluation (core.py:105-134) is outside this backend")
+        keys = ["constraints", "lower_bounds", "upper_bounds"]
+        if (constraints is not None) and ((not isinstance(constraints, dict)) or not all(k in constraints for k in keys)):
+            raise Exception(f"Error: provided constraints must be a dictionary with keys {keys} and list items.")
         self.nx, self.ny, self.priors, self.target = nx, ny, priors, target
         self.parallel, self.nproc, self.pulse = parallel, nproc, pulse
         self.constraints, self.verbose = constraints, verbose
@@ -119,6 +122,33 @@ class GPMCMC(ConsumersMixin):
             return np.empty((0, self.nx)), np.empty((0, self.ny))
         return np.array(keep_x), np.array(ys)
 
+    def __check_constraints(self, xsamps):
+        """core.py:218-246, applied to proposed samples before the target runs (lhc.py:30-31).  As in the reference the
+        mask entry of a sample is overwritten by every constraint in turn, so the LAST constraint decides (quirk kept)."""
+        n0 = len(xsamps)
+        mask = np.ones(n0, dtype=bool)
+        for i, xj in enumerate(xsamps):
+            for e, f in enumerate(self.constraints["constraints"]):
+                flag = True
+                res = f(xj)
+                lo, hi = self.constraints["lower_bounds"][e], self.constraints["upper_bounds"][e]
+                if isinstance(lo, list):
+                    for k, b in enumerate(lo):
+                        if res[k] < b:
+                            flag = False
+                    for k, b in enumerate(hi):
+                        if res[k] > b:
+                            flag = False
+                elif res < lo or res > hi:
+                    flag = False
+                mask[i] = flag
+                if not flag:
+                    print(f"Sample {i + 1} with x values {xj} removed due to invalidaing constraint {e + 1}.")
+        xsamps = xsamps[mask]
+        if len(xsamps) < n0:
+            print(f"{n0 - len(xsamps)} samples removed due to violating constraints.")
+        return xsamps
+
     def __reconvert(self):
         self.xc = np.empty_like(self.x)
         self.yc = np.empty_like(self.y)
@@ -140,6 +170,8 @@ class GPMCMC(ConsumersMixin):
         if self.verbose:
             print(f"Evaluating {nsamps} latin hypercube samples...")
         xs = latin_sample(self.priors, nsamps, seed)
+        if self.constraints is not None:
+            xs = self.__check_constraints(xs)
         xs, ys = self.__evaluate(xs, self.target)
         self.x = np.r_[self.x, xs]
         self.y = np.r_[self.y, ys]
@@ -375,7 +407,9 @@ class GPMCMC(ConsumersMixin):
         data = None
         if method == "map":
             best, mp = -np.inf, None
-            for _ in range(max(int(restarts), 1)):
+            nrest = max(int(restarts), 1)
+            last_error = None
+            for _ in range(nrest):
                 # the reference builds a random start and never passes it (gpmcmc.py:330-332): every
                 # restart begins at the model's initial point, so they coincide; kept as is
                 try:
@@ -384,13 +418,18 @@ class GPMCMC(ConsumersMixin):
                         q0 = model.q_from_point(kwargs["start"])
                     q, info = find_MAP(fun_map, q0, progressbar=kwargs.get("progressbar", False),
                                        maxeval=kwargs.get("maxeval", 5000))
-                except Exception:
+                except RuntimeError:
+                    raise  # device / library errors (MiGP._check) are never a "failed restart"
+                except Exception as e:
+                    if nrest == 1:
+                        raise  # single fit: the exception propagates as in gpmcmc.py:343-345
                     print("Restart failed")
+                    last_error = e
                     continue
                 if info["logp"] > best:
                     best, mp, data = info["logp"], model.point_dict(q), info
             if mp is None:
-                raise RuntimeError("find_MAP failed")
+                raise RuntimeError("find_MAP failed in every restart") from last_error
             if self.verbose:
                 print(f"MAP: {data['nfev']} evaluations, logp = {data['logp']:,.5g}")
         elif method == "none":

@@ -4,15 +4,22 @@ on the Matern-5/2, N=16384, d=16 workload, one replica (one independent hyper-pa
 A "step" is one LML evaluation at a fresh theta: covariance assembly -> blocked fp64 Cholesky with
 the forward solve folded in -> log-det / quadratic-form reduction, with X and y resident in HBM.
 Ranks are independent chains (SURVEY.md section 8e "replicas only": MAP restarts / MCMC chains,
-gpmcmc.py:328-343,351), so there is no data-path collective and scaling is weak.
+gpmcmc.py:328-343,351), so there is no data-path collective in the timed region and scaling is weak.
+The same JSON line carries a ``sharded`` sub-record: ONE covariance (BASELINE config 4: RBF, N=65536,
+d=32) column-panel sharded over all ranks with one RCCL broadcast per panel (strong scaling).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N ...        # starts N ranks itself (torch.distributed.run) when WORLD_SIZE is unset
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -21,8 +28,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-FP64_PEAK_TFLOPS = 78.6  # AMD MI355X datasheet fp64 vector = matrix peak; measured bare-issue rate of
-# v_mfma_f64_4x4x4_4b_f64 is 74.8 TFLOP/s (profiles/r01_probe_fp64_rates.txt)
+FP64_PEAK_TFLOPS = 78.6  # AMD MI355X datasheet fp64 vector = matrix peak (256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz);
+# measured bare-issue rate of v_mfma_f64_16x16x4_f64 with VGPR accumulators: 77.0 TFLOP/s (profiles/r01_probe_mfma_f64_16x16x4.txt)
 
 
 def synth_problem(N, d, seed=0):
@@ -48,15 +55,8 @@ def theta_sequence(d, steps, seed):
     return out
 
 
-def cpu_baseline(N, d, kernel, budget_s=25.0):
-    """Oracle (NumPy/SciPy restatement of the reference's PyMC->SciPy LAPACK path) timed on this
-    box's host cores on a bounded sample: the same workload at N_s < N, extrapolated to N by
-    N^2 (assembly) and N^3 (dpotrf), because one N=16384 evaluation alone is ~1 min of CPU."""
-    from oracle import gp_oracle as orc
-    import scipy.linalg as sla
-
-    # BLAS threads = the cores this process may actually run on (the GPU box gives a CPU share that is
-    # smaller than the machine; oversubscribing OpenBLAS makes dpotrf several times slower)
+def host_cores():
+    """Cores this process may actually use: affinity mask, capped by the cgroup CPU quota."""
     try:
         ncpu = len(os.sched_getaffinity(0))
     except Exception:
@@ -67,7 +67,19 @@ def cpu_baseline(N, d, kernel, budget_s=25.0):
             ncpu = max(1, min(ncpu, int(int(quota) / int(period))))
     except Exception:
         pass
-    ncpu = min(ncpu, 16)  # a one-GPU box's CPU share (more OpenBLAS threads than cores only slows dpotrf down)
+    return ncpu
+
+
+def cpu_baseline(N, d, kernel, full=True):
+    """Oracle (NumPy/SciPy restatement of the reference's PyMC -> SciPy LAPACK path) timed on this box's host
+    cores.  ``full``: ONE LML evaluation at the benchmark's own N (measured, ~1 min of CPU at N=16384); the
+    LML + gradient leg is timed at N/4 and scaled by N^3 (a full one is ~3x the LML: too long for a default run).
+    BLAS threads = the box's CPU share for one GPU (16), not the machine's core count: OpenBLAS with more threads
+    than the cgroup quota allows is several times slower."""
+    from oracle import gp_oracle as orc
+    import scipy.linalg as sla
+
+    ncpu = min(host_cores(), 16)
     try:
         import threadpoolctl
 
@@ -75,71 +87,130 @@ def cpu_baseline(N, d, kernel, budget_s=25.0):
         threads = min(ncpu, max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] + [1]))
     except Exception:
         threads = ncpu
-    Ns = 4096
-    X, y = orc.synth_problem(Ns, d, seed=0)
-    theta = orc.synth_theta(d)
-    kerns = [kernel]
-    t0 = time.perf_counter()
-    K = orc.noisy_cov(X, kerns, [], theta)
-    t1 = time.perf_counter()
-    L = sla.cholesky(K, lower=True)
-    t2 = time.perf_counter()
-    beta = sla.solve_triangular(L, y, lower=True)
-    _ = -0.5 * beta @ beta - np.log(np.diag(L)).sum()
-    t3 = time.perf_counter()
-    t_asm, t_chol, t_solve = t1 - t0, t2 - t1, t3 - t2
+
+    def one(Ns):
+        X, y = orc.synth_problem(Ns, d, seed=0)
+        theta = orc.synth_theta(d)
+        t0 = time.perf_counter()
+        K = orc.noisy_cov(X, [kernel], [], theta)
+        t1 = time.perf_counter()
+        L = sla.cholesky(K, lower=True, overwrite_a=True, check_finite=False)
+        t2 = time.perf_counter()
+        beta = sla.solve_triangular(L, y, lower=True, check_finite=False)
+        _ = -0.5 * beta @ beta - np.log(np.diag(L)).sum()
+        t3 = time.perf_counter()
+        return t1 - t0, t2 - t1, t3 - t2
+
+    Ns = N if full else min(N, 4096)
+    t_asm, t_chol, t_solve = one(Ns)
     s = N / Ns
     t_full = t_asm * s ** 2 + t_chol * s ** 3 + t_solve * s ** 2
+    # LML + analytic gradient (K^-1 via dpotri-style solves + contraction), bounded sample
+    Ng = min(N, 4096)
+    Xg, yg = orc.synth_problem(Ng, d, seed=0)
+    t0 = time.perf_counter()
+    orc.lml_grad(Xg, yg, [kernel], [], orc.synth_theta(d))
+    t_grad = (time.perf_counter() - t0) * (N / Ng) ** 3
+    how = "measured at the full size, one evaluation" if Ns == N else f"measured at N={Ns}, extrapolated by N^2/N^3"
     return {
         "value": 1.0 / t_full,
         "unit": "evals/s",
         "cores": int(threads),
         "kind": "port",
-        "sample": f"oracle LML at N={Ns} d={d} {kernel}: assembly {t_asm:.2f}s dpotrf {t_chol:.2f}s "
-                  f"({Ns ** 3 / 3 / t_chol * 1e-9:.0f} GFLOP/s) solve {t_solve:.3f}s; extrapolated to N={N} "
-                  f"by N^2/N^3 -> {t_full:.1f}s per eval",
+        "measured_at_full_size": bool(Ns == N),
+        "sample": f"oracle LML at N={Ns} d={d} {kernel} ({how}): assembly {t_asm:.2f}s dpotrf {t_chol:.2f}s "
+                  f"({Ns ** 3 / 3 / t_chol * 1e-9:.0f} GFLOP/s) solve {t_solve:.3f}s -> {t_full:.1f}s per eval; "
+                  f"BLAS threads {threads} of {os.cpu_count()} machine cores (the one-GPU box's CPU share)",
+        "lml_grad_value": 1.0 / t_grad,
+        "lml_grad_sample": f"oracle LML+grad at N={Ng}, scaled by (N/{Ng})^3 -> {t_grad:.0f}s per eval",
     }
 
 
-def sharded_main(args, X, y, rank, world, dev):
-    """Strong-scaling variant: every rank owns a block-cyclic share of the 512/1024-column panels of ONE
-    covariance (andvaranaut_amd/distributed.py); one broadcast per panel over RCCL."""
+# ------------------------------------------------------------------------------------------------ launching ranks
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(args):
+    """``--gpus N`` without a launcher: start N fresh ranks (one per GPU) BEFORE this process touches HIP --
+    torch.cuda.device_count() does not initialise the runtime on this image -- and exit with their code."""
+    import torch
+
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        sys.exit(f"bench.py --gpus {args.gpus}: needs {args.gpus} GPUs, this box has {have}")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.run(cmd).returncode)
+
+
+class Deadline:
+    """Safety net around the sharded sub-record (its RCCL transport cannot be rehearsed on a one-GPU box): if it
+    has not finished in time, rank 0 prints the line it already has and every rank leaves."""
+
+    def __init__(self, seconds, on_expire):
+        self.timer = threading.Timer(seconds, on_expire)
+        self.timer.daemon = True
+
+    def __enter__(self):
+        self.timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.timer.cancel()
+        return False
+
+
+# ------------------------------------------------------------------------------------------------ sharded (config 4)
+def sharded_record(args, rank, world, dev, N, d, kernel, steps, warmup, grad=False):
+    """ONE covariance sharded over all ranks (andvaranaut_amd/distributed.py): block-cyclic column panels, the owner
+    factors a panel and broadcasts it (RCCL), every rank updates the panels it owns.  Same theta on every rank."""
     import torch
     import torch.distributed as dist
 
     from andvaranaut_amd.distributed import DistGP
 
-    N, d = X.shape
-    gp = DistGP(X, y, args.kernel, device=dev.index)
-    thetas = theta_sequence(d, args.warmup + args.steps, seed=0)  # same theta on every rank
-    step = (lambda th: gp.lml_grad(th)[0]) if args.grad else gp.lml
-    for i in range(args.warmup):
+    X, y = synth_problem(N, d, seed=0)
+    gp = DistGP(X, y, kernel, device=dev.index)
+    thetas = theta_sequence(d, warmup + steps, seed=0)
+    for i in range(len(thetas)):  # config 4 is RBF at d=32: keep cond(K) in the benchmark regime (SURVEY 8d)
+        thetas[i][-2] = 1e-4
+    step = (lambda th: gp.lml_grad(th)[0]) if grad else gp.lml
+    for i in range(warmup):
         step(thetas[i])
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
+    gp.bytes_broadcast = 0
     t0 = time.perf_counter()
-    vals = [step(thetas[args.warmup + i]) for i in range(args.steps)]
+    vals = [step(thetas[warmup + i]) for i in range(steps)]
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    assert all(np.isfinite(v) for v in vals)
-    if rank == 0:
-        print(json.dumps({
-            "metric": "gp_lml_grad_evals_per_s" if args.grad else "gp_lml_evals_per_s", "value": args.steps / elapsed,
-            "unit": "evals/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.kernel} GP LML eval, ONE covariance N={N} d={d} sharded over {world} GPU(s)",
-                       "N": N, "d": d, "kernel": args.kernel, "parallelism": f"column-panel ({gp.pw} columns) block-cyclic x{world}"},
-            "cholesky_tflops_whole_eval": (N ** 3 / 3.0) / (elapsed / args.steps) * 1e-12}), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    ok = all(np.isfinite(v) for v in vals)
+    flops = (N ** 3 / 3.0) * (3.0 if grad else 1.0)
+    rec = {
+        "metric": "gp_lml_grad_evals_per_s" if grad else "gp_lml_evals_per_s",
+        "workload": f"{kernel} GP LML{'+grad' if grad else ''}, ONE covariance N={N} d={d} sharded over {world} GPU(s)",
+        "scaling": "strong", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "value": steps / elapsed, "unit": "evals/s", "ms_per_step": elapsed / steps * 1e3,
+        "tflops_whole_eval": flops / (elapsed / steps) * 1e-12,
+        "frac_of_fp64_peak_all_gpus": flops / (elapsed / steps) * 1e-12 / (FP64_PEAK_TFLOPS * world),
+        "parallelism": f"column-panel ({gp.pw} columns) block-cyclic x{world}, owner factors + RCCL broadcast, look-ahead 1",
+        "bytes_broadcast_per_step": gp.bytes_broadcast / max(steps, 1),
+        "collectives": "rccl" if (dist.is_initialized() and dist.get_backend() == "nccl") else "none (single process)",
+        "finite": bool(ok), "lml": float(vals[-1]),
+    }
+    del gp
+    torch.cuda.empty_cache()
+    return rec
 
 
 def main():
@@ -147,36 +218,71 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=16384)
-    ap.add_argument("--d", type=int, default=16)
-    ap.add_argument("--kernel", default="Matern52")
+    ap.add_argument("--n", type=int, default=None, help="default 16384 (replicas) / --sharded-n (with --sharded)")
+    ap.add_argument("--d", type=int, default=None, help="default 16 / --sharded-d")
+    ap.add_argument("--kernel", default=None, help="default Matern52 / --sharded-kernel")
     ap.add_argument("--panel-tiles", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-sample", action="store_true", help="time the CPU oracle at N=4096 and extrapolate (fast)")
     ap.add_argument("--roofline-steps", type=int, default=3)
-    ap.add_argument("--sharded", action="store_true", help="ONE covariance sharded over all ranks (strong scaling, panel broadcast)")
+    ap.add_argument("--sharded", action="store_true", help="the whole line is the sharded (strong-scaling) workload")
+    ap.add_argument("--no-sharded", action="store_true", help="skip the sharded sub-record")
+    ap.add_argument("--sharded-n", type=int, default=65536)
+    ap.add_argument("--sharded-d", type=int, default=32)
+    ap.add_argument("--sharded-kernel", default="RBF")
+    ap.add_argument("--sharded-steps", type=int, default=2)
+    ap.add_argument("--sharded-timeout", type=float, default=420.0)
     ap.add_argument("--grad", action="store_true", help="with --sharded: time LML + gradient (sharded K^-1) instead of the LML")
+    ap.add_argument("--grad-steps", type=int, default=5, help="LML + gradient evaluations timed after the LML region (0: skip)")
     ap.add_argument("--no-lookahead", action="store_true", help="disable the look-ahead stream everywhere (profiling aid)")
     args = ap.parse_args()
+
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        spawn_ranks(args)  # does not return
+    world = int(env_world or "1")
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if torch.cuda.device_count() < (local_rank + 1):
+        sys.exit(f"bench.py: rank {rank} needs GPU {local_rank}, this box has {torch.cuda.device_count()}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # One process group in every configuration (world 1 included), backend nccl = RCCL: the barrier / MAX reduction
+    # of the timed region and the sharded sub-record's panel broadcasts go through it.
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world == 1:
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    dist.init_process_group(backend="nccl", device_id=dev)
+    assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
     from andvaranaut_amd import MiGP
 
-    N, d = args.n, args.d
-    X, y = synth_problem(N, d, seed=0)
     if args.sharded:
-        return sharded_main(args, X, y, rank, world, dev)
-    gp = MiGP(X, y, args.kernel, device=local_rank, panel_tiles=args.panel_tiles, need_grad=False)
+        rec = sharded_record(args, rank, world, dev, args.n or args.sharded_n, args.d or args.sharded_d,
+                             args.kernel or args.sharded_kernel, args.steps, args.warmup, grad=args.grad)
+        if rank == 0:
+            line = {"metric": rec["metric"], "value": rec["value"], "unit": "evals/s", "n_gpus": world, "rccl_ranks": dist.get_world_size(),
+                    "steps": args.steps, "warmup": args.warmup, "ms_per_step": rec["ms_per_step"], "higher_is_better": True,
+                    "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                    "config": {"workload": rec["workload"], "parallelism": rec["parallelism"]}, "sharded": rec}
+            print(json.dumps(line), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+
+    N, d = args.n or 16384, args.d or 16
+    args.kernel = args.kernel or "Matern52"
+    X, y = synth_problem(N, d, seed=0)
+    want_grad = args.grad_steps > 0
+    gp = MiGP(X, y, args.kernel, device=local_rank, panel_tiles=args.panel_tiles, need_grad=want_grad)
     thetas = theta_sequence(d, args.warmup + args.steps, seed=rank)
     if args.no_lookahead:
         gp.set_option(0, 0)
@@ -184,21 +290,39 @@ def main():
     for i in range(args.warmup):
         gp.lml(thetas[i])
     torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
+    dist.barrier()
     t0 = time.perf_counter()
     vals = []
     for i in range(args.steps):
         vals.append(gp.lml(thetas[args.warmup + i]))  # synchronous on return (stream-synchronised)
     torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
+    dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
     assert all(np.isfinite(v) for v in vals), "non-finite LML in the timed region"
+    state = gp.timers()  # graph_kept / graph_dropped / fused_retries of the timed region's handle
+
+    # LML + gradient (the MAP loop of BASELINE config 3 and every NUTS leapfrog step): same handle, same thetas
+    grad_rec = None
+    if want_grad:
+        gp.lml_grad(thetas[0])
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        tg = time.perf_counter()
+        ng = min(args.grad_steps, len(thetas))
+        for i in range(ng):
+            v, g = gp.lml_grad(thetas[i])
+            assert np.isfinite(v) and np.all(np.isfinite(g))
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        tg = torch.tensor([time.perf_counter() - tg], dtype=torch.float64, device=dev)
+        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+        tg = float(tg.item()) / ng
+        grad_rec = {"lml_grad_evals_per_s": world / tg, "ms_per_eval": tg * 1e3, "steps": ng,
+                    "algorithmic_flops": "N^3 (factor N^3/3 + L^-T N^3/3 + K^-1 = U U^T N^3/3)",
+                    "tflops_whole_eval": N ** 3 / tg * 1e-12, "frac_of_fp64_peak": N ** 3 / tg * 1e-12 / FP64_PEAK_TFLOPS}
 
     # Roofline pass (rank 0): the same evaluations again with HIP events on the handle's own stream
     # around every phase and every GEMM launch.  Look-ahead is switched off for this pass so that
@@ -217,7 +341,11 @@ def main():
                 acc[k] += tm[k]
         gp.set_profiling(0)
         gp.set_option(0, 0 if args.no_lookahead else 1)
+    gp.close()
+    del gp
+    torch.cuda.empty_cache()
 
+    line = None
     if rank == 0:
         steps = args.steps
         # dominant kernel = gemm_f64_kernel_b (128x128 tiles); the 64x64-tile kernel that serves the small
@@ -225,18 +353,25 @@ def main():
         gemm_avg_ms = acc["gemm_b_ms"] / max(acc["gemm_b_launches"], 1.0)
         achieved = acc["gemm_b_flops"] / (acc["gemm_b_ms"] * 1e-3) * 1e-12 if acc["gemm_b_ms"] > 0 else 0.0
         all_gemm = acc["gemm_flops"] / (acc["gemm_ms"] * 1e-3) * 1e-12 if acc["gemm_ms"] > 0 else 0.0
-        traffic = None
+        traffic, traffic_note = None, "profiles/gemm_traffic.json missing"
         tfile = os.path.join(ROOT, "profiles", "gemm_traffic.json")
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+                tj = json.load(open(tfile))
+                traffic = tj.get("hbm_bytes_per_launch")
+                src = os.path.join(ROOT, "andvaranaut_amd", "csrc", "gemm_f64.hip")
+                sha = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
+                traffic_note = ("PMC passes of tools/pmc_traffic.sh on this kernel source" if tj.get("gemm_src_sha16") == sha
+                                else f"STALE: measured on gemm_f64.hip {tj.get('gemm_src_sha16')}, current {sha}")
+            except Exception as e:  # noqa: BLE001
+                traffic_note = f"unreadable: {e}"
+        asm_bytes = 8.0 * (N // 64) * (N // 64 + 1) / 2 * 64 * 64 + 8.0 * N * d
         line = {
             "metric": "gp_lml_evals_per_s",
             "value": world * steps / elapsed,
             "unit": "evals/s",
             "n_gpus": world,
+            "rccl_ranks": dist.get_world_size(),
             "steps": steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / steps * 1e3,
@@ -248,29 +383,48 @@ def main():
             "config": {"workload": f"{args.kernel} GP LML eval (assembly + Cholesky + solve), N={N} d={d}, LHS inputs",
                        "N": N, "d": d, "kernel": args.kernel, "parallelism": f"replicas x{world} (one chain per GPU)"},
             "cholesky_tflops_whole_eval": (N ** 3 / 3.0) / (elapsed / steps) * 1e-12,
+            "cholesky_frac_of_peak_whole_eval": (N ** 3 / 3.0) / (elapsed / steps) * 1e-12 / FP64_PEAK_TFLOPS,
+            "graph_kept": state.get("graph_kept"), "graph_dropped": state.get("graph_dropped"),
+            "fused_retries": state.get("fused_retries"),
+            "lml_grad": grad_rec,
             "roofline_pass": {"steps": rsteps, "lookahead": False,
                               "phase_ms": {"assemble": acc["assemble_ms"] / rsteps, "cholesky": acc["cholesky_ms"] / rsteps,
                                            "gemm_in_cholesky": acc["gemm_ms"] / rsteps}},
             # K1/K2: lower-triangle 64x64 tiles written once + X read once (8*N*d): HBM-side figure the
             # north star asks for next to the MFMA one
-            "assembly": {"kernel": "assemble_kernel", "ms": acc["assemble_ms"] / rsteps,
-                         "algorithmic_bytes": 8.0 * (N // 64) * (N // 64 + 1) / 2 * 64 * 64 + 8.0 * N * d,
-                         "achieved_GBps": (8.0 * (N // 64) * (N // 64 + 1) / 2 * 64 * 64 + 8.0 * N * d)
-                         / (acc["assemble_ms"] / rsteps * 1e-3) * 1e-9, "peak_GBps": 8000.0},
+            "assembly": {"kernel": "assemble_kernel", "ms": acc["assemble_ms"] / rsteps, "algorithmic_bytes": asm_bytes,
+                         "achieved_GBps": asm_bytes / (acc["assemble_ms"] / rsteps * 1e-3) * 1e-9, "peak_GBps": 8000.0},
             "roofline": {"kernel": "gemm_f64_kernel_b (SYRK trailing/panel updates, v_mfma_f64_16x16x4_f64)",
                          "bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
+                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_note,
                          "avg_launch_ms": gemm_avg_ms, "launches_per_step": acc["gemm_b_launches"] / rsteps,
                          "flop_share_of_all_gemm": acc["gemm_b_flops"] / max(acc["gemm_flops"], 1.0),
                          "all_gemm_kernels_tflops": all_gemm, "all_gemm_launches_per_step": acc["gemm_launches"] / rsteps},
         }
+
+    # sharded sub-record (strong scaling, BASELINE config 4) under a deadline: the replicas' line survives a stuck exchange
+    if not args.no_sharded:
+        def expire():
+            if rank == 0 and line is not None:
+                line["sharded"] = {"error": f"not finished after {args.sharded_timeout:.0f} s (rank 0 gave up waiting)"}
+                print(json.dumps(line), flush=True)
+            os._exit(0 if rank == 0 else 3)
+
+        with Deadline(args.sharded_timeout, expire):
+            try:
+                rec = sharded_record(args, rank, world, dev, args.sharded_n, args.sharded_d, args.sharded_kernel,
+                                     args.sharded_steps, 1)
+            except Exception as e:  # noqa: BLE001 - the replicas' numbers must still be reported
+                rec = {"error": f"{type(e).__name__}: {e}"}
+        if rank == 0:
+            line["sharded"] = rec
+
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(N, d, args.kernel)
+            line["cpu_baseline"] = cpu_baseline(N, d, args.kernel, full=not args.cpu_baseline_sample)
         print(json.dumps(line), flush=True)
-    gp.close()
-    if world > 1:
-        dist.barrier()  # rank 0's roofline pass runs after the timed region: leave together
-        dist.destroy_process_group()
+    dist.barrier()  # rank 0's roofline pass / CPU baseline run after the timed region: leave together
+    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

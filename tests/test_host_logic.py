@@ -50,6 +50,49 @@ def test_tutorial_conversion_pins():
     assert np.allclose(u.rev(u.con(np.array([0.3, 1.9]))), [0.3, 1.9])
 
 
+def _tutorial_target(x):
+    """The tutorial's example target (tutorial.ipynb cell 5): 2 inputs, 1 output."""
+    x1, x2 = x
+    return np.array([x1 ** 2 - x1 - x2 ** 2 * x1 + x2])
+
+
+def test_tutorial_pins_both_rows_through_the_facade():
+    """Every number tutorial.ipynb cell 20 records: set_data on the facade converts x with the same uniform / normal
+    conrevs (gpmcmc.py:235-237) and leaves y unconverted (yconrevs=[None], gpmcmc.py:279); the recorded y are the
+    target's values at the recorded x (8 printed decimals -> 2e-8)."""
+    from andvaranaut_amd import GPMCMC
+    from andvaranaut_amd.transform import normal, uniform
+
+    pins = load_json("tutorial_pins.json")
+    c20 = pins["cell20"]
+    space = [st.uniform(loc=0, scale=2), st.uniform(loc=1, scale=0.5)]
+    g = GPMCMC(kernel="RBF", noise=False, xconrevs=[uniform(space[0]), normal(space[1])], yconrevs=[None], nx=2, ny=1,
+               priors=space, target=_tutorial_target, parallel=False, nproc=1, verbose=False)
+    x, y = np.array(c20["x"]), np.array(c20["y"])
+    g.set_data(x, y)
+    assert np.abs(g.xc - np.array(c20["xc"])).max() < 5e-8
+    assert np.abs(g.yc - np.array(c20["yc"])).max() == 0.0
+    ytar = np.array([_tutorial_target(r) for r in x])
+    assert np.abs(ytar - y).max() < 2e-8
+
+
+def test_tutorial_target_pairs():
+    """tutorial.ipynb cells 8 / 10: eight (x, y) pairs the reference's LHC.sample recorded for its example target;
+    GPMCMC.sample evaluates the target the same way (core.py:109-114 serial path)."""
+    pins = load_json("tutorial_pins.json")["test_fun_pairs"]
+    x, y = np.array(pins["x"]), np.array(pins["y"])
+    got = np.array([_tutorial_target(r) for r in x])
+    assert np.abs(got - y).max() < 2e-8
+    from andvaranaut_amd import GPMCMC
+
+    space = [st.uniform(loc=0, scale=2), st.uniform(loc=1, scale=0.5)]
+    g = GPMCMC(kernel="RBF", noise=False, nx=2, ny=1, priors=space, target=_tutorial_target, parallel=False, nproc=1,
+               verbose=False)
+    g.sample(4, seed=0)
+    assert g.x.shape == (4, 2) and np.abs(g.y - np.array([_tutorial_target(r) for r in g.x])).max() == 0.0
+    assert np.all((g.x[:, 0] >= 0) & (g.x[:, 0] <= 2) & (g.x[:, 1] >= 1) & (g.x[:, 1] <= 1.5))
+
+
 def _oracle_callable(X, y, kerns, ops):
     return lambda theta: orc.lml_grad(X, y, kerns, ops, theta)
 
@@ -191,6 +234,35 @@ def test_facade_validates_arguments_and_fails_loudly_without_a_gpu():
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError):  # no CPU fallback for the hot path
             g.fit()
+
+
+def test_constraints_filter_proposed_samples_like_the_reference(capsys):
+    """core.py:218-246 through lhc.py:30-31: samples violating the constraint are dropped before the target runs;
+    the reference's quirk that the last constraint's verdict overwrites earlier ones is kept."""
+    from andvaranaut_amd import GPMCMC
+
+    priors = [st.uniform(loc=0, scale=2), st.uniform(loc=1, scale=0.5)]
+    calls = []
+
+    def fun(x):
+        calls.append(x.copy())
+        return np.array([x[0] + x[1]])
+
+    with pytest.raises(Exception, match="constraints must be a dictionary"):
+        GPMCMC(nx=2, ny=1, priors=priors, target=fun, constraints=[lambda x: x[0]])
+    with pytest.raises(Exception, match="constraints must be a dictionary"):
+        GPMCMC(nx=2, ny=1, priors=priors, target=fun, constraints={"constraints": []})
+    cons = {"constraints": [lambda x: x[0]], "lower_bounds": [0.0], "upper_bounds": [1.0]}
+    g = GPMCMC(nx=2, ny=1, priors=priors, target=fun, constraints=cons, verbose=False)
+    g.sample(40, seed=3)
+    assert 0 < g.nsamp < 40 and np.all(g.x[:, 0] <= 1.0) and len(calls) == g.nsamp
+    assert "samples removed due to violating constraints" in capsys.readouterr().out
+    # list-valued bounds and two constraints: only the LAST constraint decides (reference quirk)
+    cons2 = {"constraints": [lambda x: x[0], lambda x: [x[1], x[0] + x[1]]], "lower_bounds": [5.0, [1.0, 0.0]],
+             "upper_bounds": [6.0, [1.25, 10.0]]}
+    g2 = GPMCMC(nx=2, ny=1, priors=priors, target=fun, constraints=cons2, verbose=False)
+    g2.sample(40, seed=4)
+    assert 0 < g2.nsamp < 40 and np.all(g2.x[:, 1] <= 1.25)  # the first constraint (x0 in [5,6]) rejects everything, yet is overwritten
 
 
 # ----------------------------------------------------------------------------------------------- warps

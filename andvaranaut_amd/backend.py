@@ -257,8 +257,9 @@ class MiGP:
                 o[2 * m + m * self.d :].reshape(m, self.d))
 
     def set_option(self, what, value):
-        """0: look-ahead on/off, 1: GEMM variant, 2: super-panel width (tiles)."""
-        self.lib.mi_gp_set_option(self.h, int(what), int(value))
+        """Per-handle tuning knobs (include/mi_gp.h: 0 look-ahead, 2 super-panel width, 7 small-tile threshold,
+        8 one-workgroup-per-CU bulk updates, 14 tile order); unknown ids raise."""
+        self._check(self.lib.mi_gp_set_option(self.h, int(what), int(value)), "mi_gp_set_option")
 
     def set_profiling(self, level):
         self.lib.mi_gp_set_profiling(self.h, int(level))

@@ -82,9 +82,9 @@ static hipError_t panel_rec(double* A, long lda, int ntr, int c0, int w, double*
   hipError_t e;
   if (w == 1) {
     double* blk = A + (long)c0 * 128 * lda + (long)c0 * 128;
-    e = launch_potrf_leaf128(blk, lda, dinv + (size_t)c0 * 2048, col_base + c0 * 128, info, st);
+    e = launch_potrf_leaf128(blk, lda, dinv + (size_t)c0 * MINV_ELEMS, col_base + c0 * 128, info, st);
     if (e != hipSuccess) return e;
-    return launch_trsm_strip128(blk, lda, dinv + (size_t)c0 * 2048, blk + 128 * lda, lda, (ntr - c0 - 1) * 128, st);
+    return launch_trsm_strip128(dinv + (size_t)c0 * MINV_ELEMS, blk + 128 * lda, lda, (ntr - c0 - 1) * 128, st);
   }
   const int w1 = w / 2, w2 = w - w1;
   e = panel_rec(A, lda, ntr, c0, w1, dinv, info, col_base, st);
@@ -126,8 +126,7 @@ extern "C" int mi_gp_lml_partial(const double* L_dev, long ld, const double* bet
 static hipError_t trsm_block_rec(const double* L, long ldl, const double* dinv, double* B, long ldb, int m, int cbase,
                                  int c0, int w, hipStream_t st) {
   if (w == 1)
-    return launch_trsm_strip128(L + (long)c0 * 128 * ldl + (long)c0 * 128, ldl, dinv + (size_t)c0 * 2048,
-                                B + (long)(c0 - cbase) * 128, ldb, m, st);
+    return launch_trsm_strip128(dinv + (size_t)c0 * MINV_ELEMS, B + (long)(c0 - cbase) * 128, ldb, m, st);
   const int w1 = w / 2, w2 = w - w1;
   hipError_t e = trsm_block_rec(L, ldl, dinv, B, ldb, m, cbase, c0, w1, st);
   if (e != hipSuccess) return e;

@@ -3,8 +3,8 @@
 // pm.gp.Marginal.marginal_likelihood (gpmcmc.py:321-323, 345, 351).
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
-#include <map>
 #include <vector>
 #include "migp_kernels.h"
 #include "../../include/mi_gp.h"
@@ -19,31 +19,28 @@ struct mi_gp_handle {
   int device;
   hipStream_t stream;    // trailing updates, assembly, reductions
   hipStream_t pstream;   // look-ahead panel factorisation (higher priority)
-  hipEvent_t ev_panel, ev_upd;
-  int lookahead;
-  int use_graph;
-  int bulk_wide_late, bulk_wide_thr;  // CU count of the persistent bulk kernel once <= thr tile columns remain
-  int bulk_wide;   // look-ahead bulk updates on the 8-wave / one-workgroup-per-CU GEMM kernel (variant C)
-  int lowocc_thr;  // trailing sizes (tile columns) at or below which bulk updates run one workgroup per CU
-  int w_thr[3];  // trailing sizes (tile columns) above which the super-panel is 16 / 8 / 4 tiles wide
-  std::map<int, hipGraphExec_t> graphs;  // captured evaluation DAGs, keyed by (what, options)
-  std::map<int, float> graph_plain_ms;   // device time of the same evaluation by plain launches, per key
-  int graph_key_last;                    // key replayed by the last evaluation (-1: none) and its slow-replay count
-  int graph_slow_count;
+  std::vector<hipEvent_t> ev_pool;  // one event per cross-stream hand-off of an evaluation (never re-recorded inside one
+  size_t ev_next;                   // evaluation: a captured DAG then holds one node pair per hand-off)
+  hipEvent_t wait_ev;               // recorded on the main stream behind the (a2) update of tile columns wait_col + 1 ..:
+  int wait_col;                     // the panel stream waits for it after the leaf + strip of tile column wait_col
+  // tuning options (mi_gp_set_option), all per handle
+  int lookahead;    // 0 never, 1 by size (default: from LOOKAHEAD_MIN_TILES tile columns on), 2 always
+  int lowocc_thr;   // trailing sizes (tile columns) at or below which bulk updates run one workgroup per CU
+  int w_thr[3];     // trailing sizes (tile columns) above which the super-panel is 16 / 8 / 4 tiles wide
+  int small_below;  // GEMM launches with fewer 128x128 tiles than this run on 64x64 tiles
+  int band_rows;    // band height of the band-column-major tile order of uniform-k trapezoid launches
   mi_gp_buffers buf;
   bool have_data;
   // handle-owned small scratch
   double* theta_dev;    // [ntheta]
   double* out_dev;      // [16] scalars
-  double* dinv_dev;     // [ntc][8][16][16]
+  double* dinv_dev;     // [ntc][128][128] explicit inverses of the diagonal blocks of L (leaf output, strip operand)
   double* alpha_dev;    // [np] K^-1 y
   double* part_dev;     // [grad_contract_blocks(n)][ntheta]
   double* gxs_dev;      // [grad_x_splits][n][d] partial dLML/dX (allocated on first mi_gp_grad_x)
   double* grad_dev;     // [ntheta]
   double* grad_host;    // pinned [ntheta]
   int* info_dev;
-  int* ready_dev;       // [ntc] leaf -> strip words of the fused launches, zeroed before every evaluation
-  int fuse_thr;         // leaf + strip in ONE launch for tile columns with at most this many columns after them (option 13)
   double* out_host;     // pinned [16]
   int* info_host;       // pinned
   double* theta_host;   // pinned
@@ -83,7 +80,6 @@ static void release_handle(mi_gp_handle* h) {
   if (h->pstream) (void)hipStreamSynchronize(h->pstream);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   (void)hipFree(h->theta_dev); (void)hipFree(h->out_dev); (void)hipFree(h->dinv_dev); (void)hipFree(h->info_dev);
-  (void)hipFree(h->ready_dev);
   (void)hipFree(h->alpha_dev); (void)hipFree(h->part_dev); (void)hipFree(h->gxs_dev); (void)hipFree(h->grad_dev);
   if (h->grad_host) (void)hipHostFree(h->grad_host);
   if (h->out_host) (void)hipHostFree(h->out_host);
@@ -91,9 +87,7 @@ static void release_handle(mi_gp_handle* h) {
   if (h->theta_host) (void)hipHostFree(h->theta_host);
   for (int i = 0; i < 8; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
   for (auto& ev : h->gemm_ev) (void)hipEventDestroy(ev);
-  for (auto& kv : h->graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);
-  if (h->ev_panel) (void)hipEventDestroy(h->ev_panel);
-  if (h->ev_upd) (void)hipEventDestroy(h->ev_upd);
+  for (auto& ev : h->ev_pool) (void)hipEventDestroy(ev);
   if (h->pstream) (void)hipStreamDestroy(h->pstream);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -138,27 +132,20 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
     e = hipStreamCreateWithPriority(&h->pstream, hipStreamNonBlocking, hi);
   }
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_panel, hipEventDisableTiming);
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_upd, hipEventDisableTiming);
+  h->ev_next = 0;
   h->lookahead = 1;
-  h->use_graph = 1;
-  h->graph_key_last = -1;
-  h->graph_slow_count = 0;
-  h->bulk_wide = 0;
-  h->bulk_wide_late = 0;
-  h->bulk_wide_thr = 0;
+  h->small_below = GemmParams().small_below;
+  h->band_rows = GemmParams().band;
   h->lowocc_thr = 64;
   h->w_thr[0] = 1 << 20; h->w_thr[1] = 72; h->w_thr[2] = 0;
   if (e == hipSuccess) e = hipMalloc(&h->theta_dev, sizeof(double) * h->ntheta);
   if (e == hipSuccess) e = hipMalloc(&h->out_dev, sizeof(double) * 16);
-  if (e == hipSuccess) e = hipMalloc(&h->dinv_dev, sizeof(double) * 2048 * (size_t)h->ntc);
+  if (e == hipSuccess) e = hipMalloc(&h->dinv_dev, sizeof(double) * MINV_ELEMS * (size_t)h->ntc);
   if (e == hipSuccess) e = hipMalloc(&h->alpha_dev, sizeof(double) * h->np);
   if (e == hipSuccess) e = hipMalloc(&h->part_dev, sizeof(double) * (size_t)grad_contract_blocks(h->n) * h->ntheta);
   if (e == hipSuccess) e = hipMalloc(&h->grad_dev, sizeof(double) * h->ntheta);
   if (e == hipSuccess) e = hipHostMalloc(&h->grad_host, sizeof(double) * h->ntheta);
   if (e == hipSuccess) e = hipMalloc(&h->info_dev, sizeof(int) * 4);
-  if (e == hipSuccess) e = hipMalloc(&h->ready_dev, sizeof(int) * (size_t)h->ntc);
-  h->fuse_thr = 64;
   if (e == hipSuccess) e = hipHostMalloc(&h->out_host, sizeof(double) * 16);
   if (e == hipSuccess) e = hipHostMalloc(&h->info_host, sizeof(int) * 4);
   if (e == hipSuccess) e = hipHostMalloc(&h->theta_host, sizeof(double) * h->ntheta);
@@ -194,37 +181,22 @@ extern "C" int mi_gp_set_data(mi_gp_handle* h, const mi_gp_buffers* b) {
   }
   h->buf = *b;
   h->have_data = true;
-  for (auto& kv : h->graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);  // captured pointers are stale
-  h->graphs.clear();
   return 0;
 }
 
-// tuning knobs: what = 0 look-ahead on/off (per handle), 1 GEMM kernel variant (process-wide),
-// 2 super-panel width in 128-column tiles
+// tuning knobs, all per handle (include/mi_gp.h lists them)
 extern "C" int mi_gp_set_option(mi_gp_handle* h, int what, int value) {
   if (!h) return -1;
-  if (what == 0) h->lookahead = value ? 1 : 0;
-  else if (what == 1) set_gemm_variant(value);
+  if (what == 0) h->lookahead = value < 0 ? 0 : value > 2 ? 2 : value;
   else if (what == 2) h->cfg.panel_tiles = value;
-  else if (what == 3) h->use_graph = value ? 1 : 0;
   else if (what >= 4 && what <= 6) h->w_thr[what - 4] = value;
-  else if (what == 7) {
-    set_gemm_small_tiles(value);
-    for (auto& kv : h->graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);  // captured launches used the old routing
-    h->graphs.clear();
-  }
-  else if (what == 14) {
-    set_gemm_band_rows(value);
-    for (auto& kv : h->graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);  // captured launches used the old order
-    h->graphs.clear();
-  }
+  else if (what == 7) h->small_below = value;
   else if (what == 8) h->lowocc_thr = value;
-  else if (what == 9) h->bulk_wide = value;
-  else if (what == 10) h->bulk_wide_late = value;
-  else if (what == 12) { set_leaf_exclusive(value); for (auto& kv : h->graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second); h->graphs.clear(); }
-  else if (what == 11) h->bulk_wide_thr = value;
-  else if (what == 13) h->fuse_thr = value;
-  else return -1;
+  else if (what == 14) h->band_rows = value;
+  else {
+    snprintf(h->err, sizeof(h->err), "mi_gp_set_option: unknown option %d", what);
+    return -1;
+  }
   return 0;
 }
 
@@ -262,10 +234,11 @@ static hipError_t prof_gemm(mi_gp_handle* h, const GemmParams& p, int ak, int bk
 
 // trapezoid update  A[r0:, c0:c0+nc] -= P P_c^T  with P = A[r0:, k0:k0+kw] (tile units)
 static hipError_t syrk_trapezoid(mi_gp_handle* h, double* A, long lda, int ntr, int r0, int nc, int k0, int kw,
-                                 hipStream_t st, int one_per_cu = 0, int wide8 = 0) {
+                                 hipStream_t st, int one_per_cu = 0) {
   GemmParams p;
   p.one_per_cu = one_per_cu;
-  p.wide8 = wide8;
+  p.small_below = h->small_below;
+  p.band = h->band_rows;
   p.A = A + (long)r0 * 128 * lda + (long)k0 * 128;
   p.B = p.A;
   p.C = A + (long)r0 * 128 * lda + (long)r0 * 128;
@@ -291,16 +264,15 @@ static hipError_t chol_panel(mi_gp_handle* h, double* A, long lda, int ntr, int 
   hipError_t e;
   if (w == 1) {
     double* blk = A + (long)c0 * 128 * lda + (long)c0 * 128;
-    double* dinv = h->dinv_dev + (size_t)c0 * 2048;
+    double* dinv = h->dinv_dev + (size_t)c0 * MINV_ELEMS;
     const int m = (ntr - c0 - 1) * 128;
-    // Fused launch where the panel chain is the critical path (saves the launch boundary and lets the strip's rows
-    // travel during the leaf: -4 % at N <= 8192).  While the bulk update is the long pole the waiting strip workgroups
-    // would only take CU slots from it (+2 % at N = 16384 when fused everywhere).
-    if (ntr - 1 - c0 <= h->fuse_thr)
-      return launch_potrf_leaf_strip128(blk, lda, dinv, c0 * 128, h->info_dev, blk + 128 * lda, lda, m, h->ready_dev + c0, st);
     e = launch_potrf_leaf128(blk, lda, dinv, c0 * 128, h->info_dev, st);
-    if (e != hipSuccess) return e;
-    return launch_trsm_strip128(blk, lda, dinv, blk + 128 * lda, lda, m, st);
+    if (e == hipSuccess) e = launch_trsm_strip128(dinv, blk + 128 * lda, lda, m, st);
+    if (e == hipSuccess && c0 == h->wait_col) {  // the super-panel's other columns are being updated on the main stream
+      h->wait_col = -1;
+      e = hipStreamWaitEvent(st, h->wait_ev, 0);
+    }
+    return e;
   }
   const int w1 = w / 2, w2 = w - w1;
   e = chol_panel(h, A, lda, ntr, c0, w1, st);
@@ -322,36 +294,68 @@ static int pick_w(const mi_gp_handle* h, int rem) {
   return rem < W ? rem : W;
 }
 
+static hipError_t next_event(mi_gp_handle* h, hipEvent_t* out) {
+  if (h->ev_next == h->ev_pool.size()) {
+    hipEvent_t ev;
+    hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e != hipSuccess) return e;
+    h->ev_pool.push_back(ev);
+  }
+  *out = h->ev_pool[h->ev_next++];
+  return hipSuccess;
+}
+
+// `to` waits for everything queued on `from` so far
+static hipError_t hand_off(mi_gp_handle* h, hipStream_t from, hipStream_t to) {
+  hipEvent_t ev;
+  hipError_t e = next_event(h, &ev);
+  if (e != hipSuccess) return e;
+  e = hipEventRecord(ev, from);
+  if (e != hipSuccess) return e;
+  return hipStreamWaitEvent(to, ev, 0);
+}
+
+// Below this many tile columns one stream is faster than two (measured, plain launches: N = 2048 1.03 vs 1.13 ms,
+// N = 4096 2.46 vs 2.48 ms, N = 8192 7.09 vs 6.45 ms): the cross-stream hand-offs cost more than the overlap returns.
+constexpr int LOOKAHEAD_MIN_TILES = 40;
+
 static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int ntc) {
-  hipStream_t T = h->stream, P = h->lookahead ? h->pstream : h->stream;
+  const bool la = h->lookahead == 2 || (h->lookahead == 1 && ntc >= LOOKAHEAD_MIN_TILES);
+  hipStream_t T = h->stream, P = la ? h->pstream : h->stream;
   hipError_t e;
 #define CKE(x) do { e = (x); if (e != hipSuccess) return e; } while (0)
-  if (P != T) {  // panel stream starts after everything already queued on the main stream (assembly)
-    CKE(hipEventRecord(h->ev_upd, T));
-    CKE(hipStreamWaitEvent(P, h->ev_upd, 0));
-  }
+  h->ev_next = 0;
+  h->wait_col = -1;
+  if (P != T) CKE(hand_off(h, T, P));  // panel stream starts after everything already queued on the main stream (assembly)
   int w = pick_w(h, ntc);
   CKE(chol_panel(h, A, lda, ntr, 0, w, P));
   for (int J = 0; J < ntc;) {
     const int n1 = J + w;  // first tile column right of this super-panel
-    if (P != T) {
-      CKE(hipEventRecord(h->ev_panel, P));
-      CKE(hipStreamWaitEvent(T, h->ev_panel, 0));
-    }
+    if (P != T) CKE(hand_off(h, P, T));  // the main stream may read super-panel J from here on
     if (n1 >= ntc) break;
     const int wn = pick_w(h, ntc - n1);
-    // (a) bring the next super-panel's columns up to date, then hand them to the panel stream
-    CKE(syrk_trapezoid(h, A, lda, ntr, n1, wn, J, w, T));
     if (P != T) {
-      CKE(hipEventRecord(h->ev_upd, T));
-      CKE(hipStreamWaitEvent(P, h->ev_upd, 0));
+      // (a1) the next super-panel's FIRST tile column on the panel stream itself: the chain goes on to its leaf without
+      //      waiting for the other wn - 1 columns (round 1 updated all wn columns on the main stream first: 40-80 us on
+      //      the critical path per super-panel).  That column was last touched by the previous step's bulk update (b)
+      //      on the main stream: wait for it first.
+      // (a2) the other columns on the main stream meanwhile; the panel stream waits for them after that leaf + strip
+      if (J > 0) CKE(hand_off(h, T, P));
+      CKE(syrk_trapezoid(h, A, lda, ntr, n1, 1, J, w, P));
+      if (wn > 1) {
+        CKE(syrk_trapezoid(h, A, lda, ntr, n1 + 1, wn - 1, J, w, T));
+        CKE(next_event(h, &h->wait_ev));
+        CKE(hipEventRecord(h->wait_ev, T));
+        h->wait_col = n1;
+      }
+    } else {
+      CKE(syrk_trapezoid(h, A, lda, ntr, n1, wn, J, w, T));
     }
     CKE(chol_panel(h, A, lda, ntr, n1, wn, P));
-    // (b) the rest of the trailing matrix, concurrently with that panel factorisation
-    // (b) runs next to the panel chain: the 8-wave kernel leaves half of every CU to it
+    // (b) the rest of the trailing matrix, concurrently with that panel factorisation; once the panel chain is the
+    // critical path the bulk update runs one workgroup per CU so that a leaf / strip workgroup fits beside it everywhere
     if (n1 + wn < ntc)
-      CKE(syrk_trapezoid(h, A, lda, ntr, n1 + wn, ntc - n1 - wn, J, w, T,
-                         (P != T && !h->bulk_wide && ntc - n1 <= h->lowocc_thr) ? 1 : 0, (P != T) ? ((ntc - n1 <= h->bulk_wide_thr) ? h->bulk_wide_late : h->bulk_wide) : 0));
+      CKE(syrk_trapezoid(h, A, lda, ntr, n1 + wn, ntc - n1 - wn, J, w, T, (P != T && ntc - n1 <= h->lowocc_thr) ? 1 : 0));
     J = n1;
     w = wn;
   }
@@ -360,8 +364,7 @@ static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int nt
 }
 
 // Kernels of one evaluation: assembly, factorisation of the augmented trapezoid [[K],[y^T]] (L ends
-// up in K_dev, beta = L^-1 y in row np), reduction.  Only kernels -- the small copies around them
-// stay outside the captured graph.
+// up in K_dev, beta = L^-1 y in row np), reduction.
 static int enqueue_factor(mi_gp_handle* h, int noise_form, bool prof) {
   if (prof) (void)hipEventRecord(h->ev[0], h->stream);
   HCK(launch_assemble(h->spec, h->theta_dev, h->buf.X_dev, h->n, h->buf.X_dev, h->n, h->buf.K_dev, h->buf.lda, h->np,
@@ -386,76 +389,30 @@ static int download_results(mi_gp_handle* h, int what) {
   return 0;
 }
 
-// Run `what` (0 factor marginal form, 1 factor conditional form, 2 factor + gradient) either by
-// replaying its captured hipGraph (the DAG is static for a handle: only theta changes, and theta
-// travels through a fixed pinned buffer) or, when profiling events are requested, by plain launches.
+static int enqueue_all(mi_gp_handle* h, int what, bool prof) {
+  if (int r = enqueue_factor(h, what == 1 ? 1 : 0, prof)) return r;
+  if (what == 2) return enqueue_gradient(h, prof);
+  return 0;
+}
+
+static int reset_flags(mi_gp_handle* h) {
+  HCK(hipMemsetAsync(h->info_dev, 0x7f, sizeof(int) * 4, h->stream), "info reset");
+  return 0;
+}
+
+// Run `what` (0 factor marginal form, 1 factor conditional form, 2 factor + gradient) as plain launches on the handle's
+// stream(s).  Round 1 replayed a captured hipGraph per evaluation; measured again in round 2 (tools/time_sizes.py) replay
+// is 1-4 % faster than plain launches from N = 4096 on and SLOWER below (N = 128: 0.104 vs 0.087 ms), its keep / drop
+// heuristic made the timing depend on the instantiation, and the HIP runtime of this stack crashes in
+// hip::Graph::UpdateStreams when executable graphs of two-stream captures come and go
+// (profiles/r02_hipgraph_updatestreams_segv.txt; tools/stress_handles.py reproduced it in seconds) -- removed.
 static int run_evaluation(mi_gp_handle* h, int what) {
   const bool prof = h->prof_level >= 1;
-  const int noise_form = (what == 1) ? 1 : 0;
   h->gemm_ev_used = 0;
   h->gemm_flops_acc = 0.0;
   HCK(hipMemcpyAsync(h->theta_dev, h->theta_host, sizeof(double) * h->ntheta, hipMemcpyHostToDevice, h->stream), "theta upload");
-  HCK(hipMemsetAsync(h->info_dev, 0x7f, sizeof(int) * 4, h->stream), "info reset");
-  HCK(hipMemsetAsync(h->ready_dev, 0, sizeof(int) * (size_t)h->ntc, h->stream), "ready reset");
-  if (prof || !h->use_graph) {
-    if (int r = enqueue_factor(h, noise_form, prof)) return r;
-    if (what == 2) { if (int r = enqueue_gradient(h, prof)) return r; }
-    return download_results(h, what);
-  }
-  const int key = what | (h->lookahead << 4) | ((h->bulk_wide ? 1 : 0) << 5) | ((h->cfg.panel_tiles & 0xff) << 8) | (gemm_variant_get() << 20) |
-                  ((h->w_thr[0] * 31 + h->w_thr[1] * 7 + h->w_thr[2] + h->lowocc_thr * 13 + h->bulk_wide * 3 + h->bulk_wide_late * 5 + h->bulk_wide_thr * 11 + h->fuse_thr * 17) & 0x7ff) << 21;
-  auto it = h->graphs.find(key);
-  if (it == h->graphs.end()) {
-    // First use: time one evaluation with plain launches, then capture + instantiate and time a
-    // replay.  On ROCm 7.2 some instantiations of this two-branch DAG replay ~40 % slower than
-    // plain launches (the look-ahead branch loses its overlap), others ~3-5 % faster; keep an
-    // executable graph only if it is not slower, retry a couple of times, else fall back (nullptr).
-    float t_plain = 0.f;
-    (void)hipEventRecord(h->ev[0], h->stream);
-    if (int r = enqueue_factor(h, noise_form, false)) return r;
-    if (what == 2) { if (int r = enqueue_gradient(h, false)) return r; }
-    (void)hipEventRecord(h->ev[1], h->stream);
-    HCK(hipStreamSynchronize(h->stream), "sync");
-    (void)hipEventElapsedTime(&t_plain, h->ev[0], h->ev[1]);
-    hipGraphExec_t keep = nullptr;
-    for (int attempt = 0; attempt < 3 && !keep; ++attempt) {
-      hipGraph_t graph = nullptr;
-      HCK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal), "begin capture");
-      int r = enqueue_factor(h, noise_form, false);
-      if (r == 0 && what == 2) r = enqueue_gradient(h, false);
-      hipError_t e = hipStreamEndCapture(h->stream, &graph);
-      if (r != 0) { if (graph) (void)hipGraphDestroy(graph); return r; }
-      if (e != hipSuccess) return hfail(h, e, "end capture");
-      hipGraphExec_t exec = nullptr;
-      e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-      (void)hipGraphDestroy(graph);
-      if (e != hipSuccess) return hfail(h, e, "graph instantiate");
-      float t_graph = 0.f;
-      HCK(hipMemsetAsync(h->info_dev, 0x7f, sizeof(int) * 4, h->stream), "info reset");
-      HCK(hipMemsetAsync(h->ready_dev, 0, sizeof(int) * (size_t)h->ntc, h->stream), "ready reset");
-      (void)hipEventRecord(h->ev[0], h->stream);
-      HCK(hipGraphLaunch(exec, h->stream), "graph launch");
-      (void)hipEventRecord(h->ev[1], h->stream);
-      HCK(hipStreamSynchronize(h->stream), "sync");
-      (void)hipEventElapsedTime(&t_graph, h->ev[0], h->ev[1]);
-      if (t_graph <= 1.05f * t_plain) keep = exec;
-      else (void)hipGraphExecDestroy(exec);
-    }
-    h->graphs.emplace(key, keep);
-    h->graph_plain_ms[key] = t_plain;
-    return download_results(h, what);  // the last run (plain or replay) left valid results
-  }
-  if (it->second == nullptr) {
-    if (int r = enqueue_factor(h, noise_form, false)) return r;
-    if (what == 2) { if (int r = enqueue_gradient(h, false)) return r; }
-    return download_results(h, what);
-  }
-  // replay, bracketed by two events: factor_internal() compares the device time with the plain-launch time
-  // recorded at capture and drops an executable graph that turns slow (seen once: 6x, ROCm 7.2)
-  (void)hipEventRecord(h->ev[0], h->stream);
-  HCK(hipGraphLaunch(it->second, h->stream), "graph launch");
-  (void)hipEventRecord(h->ev[1], h->stream);
-  h->graph_key_last = key;
+  if (int r = reset_flags(h)) return r;
+  if (int r = enqueue_all(h, what, prof)) return r;
   return download_results(h, what);
 }
 
@@ -470,21 +427,8 @@ static int factor_internal(mi_gp_handle* h, const double* theta, int what) {
     h->theta_host[i] = theta[i];
   }
   const bool prof = h->prof_level >= 1;
-  h->graph_key_last = -1;
   if (int r = run_evaluation(h, what)) return r;
   HCK(hipStreamSynchronize(h->stream), "stream sync");
-  if (h->graph_key_last >= 0) {
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, h->ev[0], h->ev[1]) == hipSuccess && ms > 1.5f * h->graph_plain_ms[h->graph_key_last] + 0.05f) {
-      if (++h->graph_slow_count >= 3) {  // three slow replays in a row: fall back to plain launches for this key
-        auto it = h->graphs.find(h->graph_key_last);
-        if (it != h->graphs.end() && it->second) { (void)hipGraphExecDestroy(it->second); it->second = nullptr; }
-        h->graph_slow_count = 0;
-      }
-    } else {
-      h->graph_slow_count = 0;
-    }
-  }
   if (prof) {
     float ms;
     (void)hipEventElapsedTime(&ms, h->ev[0], h->ev[1]); h->t_assemble_ms = ms;
@@ -510,10 +454,6 @@ static int factor_internal(mi_gp_handle* h, const double* theta, int what) {
     }
   }
   const int info = h->info_host[0];
-  if (info < 0) {  // only the bounded wait of a fused leaf + strip launch writes a negative value
-    snprintf(h->err, sizeof(h->err), "a strip workgroup gave up waiting for its leaf (fused launch, code %d)", info);
-    return -2;
-  }
   if (info != 0x7f7f7f7f) return info;  // 1-based index of the first bad pivot
   return 0;
 }
@@ -556,6 +496,7 @@ static hipError_t gemm_call(mi_gp_handle* h, int ak, int bk, const double* A, lo
   p.A = A; p.B = B; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.strideA = sA; p.strideB = sB; p.strideC = sC;
   p.mt = mt; p.nt = nt; p.k = k; p.tri = tri; p.kmode = kmode; p.alpha = alpha; p.beta = beta;
+  p.small_below = h->small_below; p.band = h->band_rows;
   return launch_gemm_f64(p, ak, bk, batch, h->stream);
 }
 
@@ -568,7 +509,7 @@ static hipError_t inverse_transpose(mi_gp_handle* h) {
   hipError_t e = launch_set_identity_blocks(U, ld, ntc, h->stream);
   if (e != hipSuccess) return e;
   // leaves: X L_kk^T = I  ->  X = L_kk^-T
-  e = launch_trsm_strip128_batched(L, ld, 128 * ld + 128, h->dinv_dev, U, ld, 128 * ld + 128, 128, ntc, h->stream);
+  e = launch_trsm_strip128_batched(h->dinv_dev, U, ld, 128 * ld + 128, 128, ntc, h->stream);
   if (e != hipSuccess) return e;
   for (int s = 1; s < ntc; s *= 2) {
     const int nfull = ntc / (2 * s);             // nodes whose second half is complete
@@ -665,8 +606,6 @@ extern "C" int mi_gp_set_diag(mi_gp_handle* h, const double* diag_dev) {
   h->diag_dev = diag_dev;
   h->factored = false;
   h->have_kinv = false;
-  for (auto& kv : h->graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);  // the pointer is baked into the captured DAG
-  h->graphs.clear();
   return 0;
 }
 
@@ -683,8 +622,7 @@ static hipError_t trsm_rec(mi_gp_handle* h, double* Bw, long ldw, int mp, int c0
   const double* L = h->buf.K_dev;
   const long lda = h->buf.lda;
   if (w == 1) {
-    return launch_trsm_strip128(L + (long)c0 * 128 * lda + (long)c0 * 128, lda, h->dinv_dev + (size_t)c0 * 2048,
-                                Bw + (long)c0 * 128, ldw, mp, h->stream);
+    return launch_trsm_strip128(h->dinv_dev + (size_t)c0 * MINV_ELEMS, Bw + (long)c0 * 128, ldw, mp, h->stream);
   }
   const int w1 = w / 2, w2 = w - w1;
   hipError_t e = trsm_rec(h, Bw, ldw, mp, c0, w1);
@@ -748,6 +686,7 @@ extern "C" int mi_gp_predict_u(mi_gp_handle* h, const double* Xnew_dev, int m, d
   p.lda = ldw; p.ldb = ld; p.ldc = ldw;
   p.strideA = p.strideB = p.strideC = 0;
   p.mt = mp / 128; p.nt = h->ntc; p.k = h->np; p.tri = 0; p.kmode = 4; p.alpha = 1.0; p.beta = 0.0;
+  p.small_below = h->small_below; p.band = h->band_rows;
   HCK(launch_gemm_f64(p, 0, 1, 1, h->stream), "K* U");
   const int nk = h->spec.nkern, d = h->spec.d;
   const double* th = h->theta_host;

@@ -154,20 +154,31 @@ __global__ void set_yrows_kernel(double* __restrict__ K, long ldk, int row0, int
 }
 
 // out[0] = LML, out[1] = sum log L_ii, out[2] = |beta|^2   (gpmcmc.py:316-318 / MvNormal.logp)
-__global__ __launch_bounds__(1024) void lml_reduce_kernel(const double* __restrict__ L, long ld,
-                                                          const double* __restrict__ beta, int n,
-                                                          double* __restrict__ out) {
-  __shared__ double s1[1024], s2[1024];
+// One 256-thread workgroup: 16 independent diagonal gathers in flight per thread (the strided diagonal walk is pure
+// latency), partial sums combined in a fixed order (bit-reproducible).
+__global__ __launch_bounds__(256) void lml_reduce_kernel(const double* __restrict__ L, long ld,
+                                                         const double* __restrict__ beta, int n,
+                                                         double* __restrict__ out) {
+  __shared__ double s1[256], s2[256];
   double a = 0.0, b = 0.0;
-  for (int i = threadIdx.x; i < n; i += 1024) {
-    a += log(L[(long)i * ld + i]);
-    const double t = beta[i];
-    b += t * t;
+  for (int i0 = threadIdx.x; i0 < n; i0 += 256 * 16) {
+    double dv[16], bv[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int i = i0 + 256 * u;
+      dv[u] = (i < n) ? L[(long)i * ld + i] : 1.0;
+      bv[u] = (i < n) ? beta[i] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      a += log(dv[u]);
+      b += bv[u] * bv[u];
+    }
   }
   s1[threadIdx.x] = a;
   s2[threadIdx.x] = b;
   __syncthreads();
-  for (int w = 512; w > 0; w >>= 1) {
+  for (int w = 128; w > 0; w >>= 1) {
     if (threadIdx.x < w) {
       s1[threadIdx.x] += s1[threadIdx.x + w];
       s2[threadIdx.x] += s2[threadIdx.x + w];
@@ -205,7 +216,7 @@ hipError_t launch_set_yrows(double* K, long ldk, int row0, int cols_pad, const d
 }
 
 hipError_t launch_lml_reduce(const double* L, long ld, const double* beta, int n, double* out, hipStream_t stream) {
-  lml_reduce_kernel<<<1, 1024, 0, stream>>>(L, ld, beta, n, out);
+  lml_reduce_kernel<<<1, 256, 0, stream>>>(L, ld, beta, n, out);
   return hipGetLastError();
 }
 

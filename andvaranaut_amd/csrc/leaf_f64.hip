@@ -1,10 +1,12 @@
 // Leaf kernels of the blocked fp64 Cholesky:
-//   potrf_leaf128 : in-place lower Cholesky of one 128x128 diagonal block, LDS resident, plus the
-//                   inverses of its eight 16x16 diagonal sub-blocks (consumed by trsm_strip128).
-//   trsm_strip128 : X * L^T = B for row strips of a 128-column panel (LAPACK dtrsm R,L,T,N), done in
-//                   transposed space so that every fp64 MFMA result tile is directly the B operand
-//                   of the next MFMA (v_mfma_f64_16x16x4_f64: D[row=(l>>4)+4r][col=l&15] is exactly
-//                   the B[k=(l>>4)+4s][col=l&15] operand layout).
+//   potrf_leaf128 : in-place lower Cholesky of one 128x128 diagonal block, LDS resident, plus its explicit
+//                   inverse M = L^-1 (128x128 lower triangular, row-major, consumed by trsm_strip128).
+//   trsm_strip128 : X * L^T = B for row strips of a 128-column panel (LAPACK dtrsm R,L,T,N) as the product
+//                   X = B * M^T: no dependency chain along the columns, so the 128 output columns of 16 rows are
+//                   split over the four waves of a workgroup and every operand is ONE global round trip
+//                   (round 1 solved by substitution over eight 16-column blocks: 144 dependent MFMAs per wave
+//                   and two dependent round trips, 17 us alone and 50+ us next to a trailing update; rocBLAS'
+//                   dtrsm inverts 128x128 diagonal blocks the same way).
 // The reference reaches the same arithmetic through scipy.linalg.cholesky / LAPACK dpotrf
 // (gpmcmc.py:313 and pm.gp.Marginal at gpmcmc.py:321-323).
 #include "migp_kernels.h"
@@ -42,7 +44,7 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
 }
 
 #ifdef LEAF_STAMPS
-__device__ unsigned long long g_leaf_stamps[8];
+__device__ unsigned long long g_leaf_stamps[16];
 #define LEAF_STAMP(i)                                                                  \
   do {                                                                                 \
     if (threadIdx.x == 0) {                                                            \
@@ -52,8 +54,19 @@ __device__ unsigned long long g_leaf_stamps[8];
       t_prev = t_;                                                                     \
     }                                                                                  \
   } while (0)
+// the same for the first thread of wave 1 (slots 8..15)
+#define LEAF_STAMP1(i)                                                                 \
+  do {                                                                                 \
+    if (threadIdx.x == 64) {                                                           \
+      unsigned long long t_;                                                           \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");        \
+      g_leaf_stamps[i] += t_ - t_prev1;                                                \
+      t_prev1 = t_;                                                                    \
+    }                                                                                  \
+  } while (0)
 #else
 #define LEAF_STAMP(i)
+#define LEAF_STAMP1(i)
 #endif
 
 __device__ __forceinline__ void wave_lds_fence() {
@@ -180,18 +193,20 @@ struct ScaleCols<16> {
 //      is ONE instruction and there is no LDS round trip per pivot;
 //  (B) rows below: X = B L16^-T, one thread per row, column-oriented substitution in registers;
 //  (C) trailing update of the remaining lower tiles on fp64 MFMA (rank 16).
-__device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, long lda, double* __restrict__ dinv,
+__device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, long lda, double* __restrict__ minv,
                                                     int col0, int* __restrict__ info, double* smem) {
   double* S = smem;                     // packed lower block-trapezoid, see soff()
   double* LdT2 = smem + LEAF_ELEMS;     // [2][16][16]  LdT[k][c] = L16[c][k] of diagonal sub-block jb (buffer jb & 1)
   double* invd = LdT2 + 2 * SB * SB;    // [128] 1 / L[c][c]
-  volatile int* sync_w = reinterpret_cast<volatile int*>(invd + LEAF);  // [0] rows published by wave 0, [1] arrivals of waves 1..3
+  volatile int* sync_w = reinterpret_cast<volatile int*>(invd + LEAF);  // [0] rows published by wave 0, [1] arrivals of waves 1..3,
+  // [2] arrivals of waves 1..3 inside the inverse phases, [3] Dinv_b ready (wave 1), [4] wave 0 done with column block jb
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
 #ifdef LEAF_STAMPS
-  unsigned long long t_prev = 0;
+  unsigned long long t_prev = 0, t_prev1 = 0;
   if (threadIdx.x == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory");
+  if (threadIdx.x == 64) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev1)::"memory");
 #endif
 
   // load the lower block-trapezoid: wave 0 takes the first 16x16 block and starts factoring it while
@@ -300,8 +315,22 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
     for (int r = 0; r < 4; ++r) S[soff(r0 + kq + 4 * r) + c0 + n] = acc[r];
   };
 
+  // tile (rb, cb) of the LDS image as MFMA operands / result:
+  //   A operand: lane holds [16 rb + n][16 cb + 4 s + kq];  B operand: [16 rb + 4 s + kq][16 cb + n];  D: [16 rb + kq + 4 r][16 cb + n]
+  const int nn = lane & 15, kq = lane >> 4;
+  auto prod = [&](double4_t acc, int arb, int acb, int brb, int bcb) {
+    const double* ap = S + soff(16 * arb + nn) + 16 * acb + kq;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[4 * s4], S[soff(16 * brb + 4 * s4 + kq) + 16 * bcb + nn], acc, 0, 0, 0);
+    return acc;
+  };
+  auto put = [&](const double4_t& v, int rb, int cb) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) S[soff(16 * rb + kq + 4 * r) + 16 * cb + nn] = v[r];
+  };
   LEAF_STAMP(0);
-  if (tid == 64) { sync_w[0] = 0; sync_w[1] = 0; }
+  if (tid == 64) { sync_w[0] = 0; sync_w[1] = 0; sync_w[2] = 0; sync_w[3] = 0; sync_w[4] = 0; }
   if (wave == 0) factor_diag(0);
   __syncthreads();
   LEAF_STAMP(1);
@@ -352,6 +381,7 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
         while (sync_w[1] < 3 * (jb + 1) || sync_w[0] < jb + 1) __builtin_amdgcn_s_sleep(1);
         wave_lds_fence();
       }
+      LEAF_STAMP1(8);
       // column block jb is final for rows >= j0: 8 pieces of 16 B per row
       for (int it = t; it < (LEAF - j0) * 8; it += 192) {
         const int r = j0 + (it >> 3), c2 = j0 + 2 * (it & 7);
@@ -362,236 +392,279 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
           else dst[0] = v.x;
         }
       }
+      LEAF_STAMP1(9);
+      // trailing tiles (tr, tc), 1 <= tr < q, tc <= tr, dealt round-robin to waves 1..3 (tile (0,0) belongs to wave 0)
+      // and processed three at a time with their MFMAs interleaved: a chain of four dependent fp64 MFMAs takes ~1k
+      // cycles, three independent chains take the same (these waves, not wave 0, were the long pole of the early
+      // iterations: 9 tiles each at jb = 0)
       const int q = LEAF / SB - 1 - jb;  // trailing tiles per dimension
-      int e = 0;
-      for (int tr = 1; tr < q; ++tr) {  // tile row 0 = tile (0,0) belongs to wave 0
-        for (int tc = 0; tc <= tr; ++tc) {
-          if ((e++ % 3) != wave - 1) continue;
-          update_tile(j0, j0 + SB + 16 * tr, j0 + SB + 16 * tc);
+      const int ntile = q * (q + 1) / 2 - 1;
+      const int ln = lane & 15, lq = lane >> 4;
+      for (int e0 = wave - 1; e0 < ntile; e0 += 9) {
+        double av[3][4], bv[3][4];
+        double4_t acc[3];
+        int r0[3], c0[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          const int e = e0 + 3 * u + 1;  // index in the full lower-triangle enumeration
+          int tr = 1;
+          while ((tr + 1) * (tr + 2) / 2 <= e) ++tr;
+          const int tc = e - tr * (tr + 1) / 2;
+          r0[u] = j0 + SB + 16 * tr;
+          c0[u] = j0 + SB + 16 * tc;
+          if (e0 + 3 * u < ntile) {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+              av[u][s4] = S[soff(r0[u] + ln) + j0 + 4 * s4 + lq];
+              bv[u][s4] = S[soff(c0[u] + ln) + j0 + 4 * s4 + lq];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[u][r] = S[soff(r0[u] + lq + 4 * r) + c0[u] + ln];
+          }
+        }
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+          for (int u = 0; u < 3; ++u)
+            if (e0 + 3 * u < ntile) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[u][s4], bv[u][s4], acc[u], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          if (e0 + 3 * u < ntile) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) S[soff(r0[u] + lq + 4 * r) + c0[u] + ln] = acc[u][r];
+          }
         }
       }
+      LEAF_STAMP1(10);
     }
     __syncthreads();
     LEAF_STAMP(3);
   }
   LEAF_STAMP(4);
-  // ---- inverses of the eight 16x16 diagonal sub-blocks: thread (b, c) solves column c of block b
-  if (tid < LEAF) {
-    const int b = tid >> 4, c = tid & 15, j0 = b * SB;
+  // ---- M = L^-1 (128x128, lower triangular) in place of L in LDS, streamed to `minv` (row-major, ld 128).
+  // (1) the eight 16x16 diagonal blocks by substitution: thread (b, c) solves column c of block b;
+  // (2) three levels of block doubling [[L11,0],[L21,L22]]^-1 = [[M11,0],[-M22 L21 M11, M22]] on MFMA: at block size
+  //     t = 1, 2, 4 tiles stage A forms T = L21 M11 (wave = tile row), stage B forms -M22 T (wave = tile column);
+  //     28 tile products per wave, the wave's up to four tiles of a stage accumulate interleaved (a dependent fp64 MFMA
+  //     chain issues at a quarter of the independent rate), results replace L21 in LDS between barriers.
+  // (An interleaved variant -- one block row of M per iteration of the loop above, in the shadow of wave 0's chain --
+  // was built and measured in round 2: 69 us instead of 36: the 16x16 inverse by substitution (4.2k cycles per block on
+  // one wave) and five LDS-word syncs per iteration outweigh the 4 us this block costs at the end.)
+  {
     double z[SB];
+    const int b = tid >> 4, c = tid & 15, j0 = b * SB;
+    if (tid < LEAF) {
 #pragma unroll
-    for (int r = 0; r < SB; ++r) z[r] = 0.0;
+      for (int r = 0; r < SB; ++r) z[r] = 0.0;
 #pragma unroll
-    for (int r = 0; r < SB; ++r) {
-      const double* lrow = S + soff(j0 + r) + j0;
-      double s0 = (r == c) ? 1.0 : 0.0, s1 = 0.0;
+      for (int r = 0; r < SB; ++r) {
+        const double* lrow = S + soff(j0 + r) + j0;
+        double s0 = (r == c) ? 1.0 : 0.0, s1 = 0.0;
 #pragma unroll
-      for (int k = 0; k < r; ++k) {  // z[k] = 0 for k < c, so no predicate is needed
-        if (k & 1) s1 = __builtin_fma(-lrow[k], z[k], s1);
-        else s0 = __builtin_fma(-lrow[k], z[k], s0);
+        for (int k = 0; k < r; ++k) {  // z[k] = 0 for k < c, so no predicate is needed
+          if (k & 1) s1 = __builtin_fma(-lrow[k], z[k], s1);
+          else s0 = __builtin_fma(-lrow[k], z[k], s0);
+        }
+        z[r] = (r >= c) ? (s0 + s1) * invd[j0 + r] : 0.0;
       }
-      z[r] = (r >= c) ? (s0 + s1) * invd[j0 + r] : 0.0;
     }
-    double* out = dinv + (long)b * SB * SB;
+    __syncthreads();  // every thread has read its diagonal block before it is overwritten
+    if (tid < LEAF) {
 #pragma unroll
-    for (int r = 0; r < SB; ++r) out[r * SB + c] = z[r];
+      for (int r = 0; r < SB; ++r) {
+        S[soff(j0 + r) + j0 + c] = z[r];  // zeros above the diagonal: the tiles are read whole as MFMA operands
+        minv[(long)(j0 + r) * LEAF + j0 + c] = z[r];
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int t = 1; t <= 4; t *= 2) {
+    const int node = wave / t, p0 = node * 2 * t, idx = wave % t;
+    double4_t res[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) res[c] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    // stage A: T[a][c] = sum_{k >= c} L[p0+t+a][p0+k] M[p0+k][p0+c], this wave owns tile row a = idx; the k-th
+    // products of its t tiles are issued together (independent accumulators)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (k < t) {
+        double av[4];
+        const double* ap = S + soff(16 * (p0 + t + idx) + nn) + 16 * (p0 + k) + kq;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) av[s4] = ap[4 * s4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (c <= k && c < t)
+              res[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s4], S[soff(16 * (p0 + k) + 4 * s4 + kq) + 16 * (p0 + c) + nn], res[c], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (c < t) put(res[c], p0 + t + idx, p0 + c);
+    __syncthreads();
+    // stage B: M21[a][c] = - sum_{k <= a} M[p0+t+a][p0+t+k] T[k][c], this wave owns tile column c = idx
+#pragma unroll
+    for (int a = 0; a < 4; ++a) res[a] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (k < t) {
+        double bv[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) bv[s4] = S[soff(16 * (p0 + t + k) + 4 * s4 + kq) + 16 * (p0 + idx) + nn];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
+            if (a >= k && a < t)
+              res[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(S[soff(16 * (p0 + t + a) + nn) + 16 * (p0 + t + k) + 4 * s4 + kq], bv[s4], res[a], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      if (a < t) {
+        const double4_t v = -res[a];
+        put(v, p0 + t + a, p0 + idx);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) minv[(long)(16 * (p0 + t + a) + kq + 4 * r) * LEAF + 16 * (p0 + idx) + nn] = v[r];
+      }
+    }
+    __syncthreads();
   }
   LEAF_STAMP(5);
 }
 
 __global__ __launch_bounds__(256, 1) void potrf_leaf128_kernel(double* __restrict__ Ablk, long lda,
-                                                                double* __restrict__ dinv, int col0,
+                                                                double* __restrict__ minv, int col0,
                                                                 int* __restrict__ info) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  potrf_leaf128_body(Ablk, lda, dinv, col0, info, smem);
+  potrf_leaf128_body(Ablk, lda, minv, col0, info, smem);
 }
 
-// X * L^T = B, in place on B (m x 128, leading dimension ldb, m multiple of 64).
-// One wave per 16 rows; tiles kept transposed: T_j[r] = B[row0 + (l&15)][16j + 4r + (l>>4)].
-// The 28 sub-diagonal 16x16 tiles of L and the 8 inverse diagonal blocks are staged once per
-// workgroup in LDS in MFMA-fragment order (tile, k4-step, lane), so every A-operand read is one
-// conflict-free ds_read_b64 of 64 consecutive doubles.  72 KB: a strip workgroup can share a CU with
-// one GEMM workgroup of the concurrent trailing update.
-constexpr int STRIP_TILES = 36;  // 28 sub-diagonal tiles of L + 8 diagonal inverses
-__device__ __forceinline__ int strip_tile(int i, int j) { return i * (i - 1) / 2 + j; }  // i > j
-
-// `ready` (fused leaf + strip launch only): word the leaf workgroup of the same launch sets once L and dinv are in
-// memory; the right-hand side rows are loaded first, so they travel while the leaf is still factoring.
-__device__ __forceinline__ void trsm_strip128_body(const double* __restrict__ Lblk, long lda,
-                                                    const double* __restrict__ dinv, double* __restrict__ B, long ldb,
-                                                    int blk, double* smem, int* ready, int* __restrict__ info) {
-  double* Lt = smem;             // [28][4][64]
-  double* Dt = smem + 28 * 256;  // [8][4][64]
+// X * L^T = B in place on B (m x 128, leading dimension ldb even, m multiple of 16 RG) as X = B * M^T with M = L^-1
+// (row-major 128 x 128, lower triangular, zeros above the diagonal of its diagonal 16x16 tiles).
+// One workgroup per 16 RG rows; wave w owns the output column blocks {w, 7 - w} (9 of the 36 lower k-blocks each: the
+// triangle is split evenly), 36 MFMAs per wave and row group.  Within a 16-wide k-block the lane quarter q = lane >> 4
+// covers k = 16 kb + 4 q + s (s = the MFMA step), so every lane fetches 4 CONTIGUOUS doubles of its row of B and of its
+// row of M per k-block: 128-byte row segments, whole cache lines, straight into MFMA operand registers -- no LDS.
+// RG row groups per workgroup reuse the wave's 9 tiles of M (RG = 1: lowest latency, 16 rows per workgroup; RG = 4: a
+// quarter of the operand traffic for tall panels).  A row group's rows are in registers in every wave (s_waitcnt +
+// barrier) before any wave stores to them: in place is safe.
+// (Round 1 also had a fused leaf + strip launch whose strip workgroups spun on a flag of the leaf workgroup: with the
+// strip down to one round trip the in-launch release / acquire hand-off costs more than the launch boundary it saved,
+// and it was the only inter-workgroup wait in the library -- removed in round 2.)
+template <int RG>
+__device__ __forceinline__ void trsm_strip128_body(const double* __restrict__ minv, double* __restrict__ B, long ldb, int blk) {
+  typedef double double2_t __attribute__((ext_vector_type(2)));
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int n = lane & 15, q = lane >> 4;
-#ifdef LEAF_STAMPS
-  unsigned long long t_prev = 0;
-  if (threadIdx.x == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory");
-#endif
-  double* Brow = B + ((long)blk * 64 + wave * 16 + n) * ldb;
-  double4_t T[8];
+  const int jb0 = wave, jb1 = 7 - wave;  // jb0 < jb1; k-blocks 0 .. jb1 are needed
+  double* Brow = B + ((long)blk * (16 * RG) + n) * ldb + 4 * q;
+  double2_t a[2][8][2];  // two row groups in flight
+  auto load_rows = [&](int set, int rg) {
+    const double* src = Brow + (long)rg * 16 * ldb;
 #pragma unroll
-  for (int j = 0; j < 8; ++j)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) T[j][r] = Brow[16 * j + 4 * r + q];
-  if (ready) {
-    if (tid == 0) {
-      // bounded wait (about a second of the 100 MHz wall clock): a lost leaf must not hang the device
-      const unsigned long long t0 = wall_clock64();
-      bool ok = true;
-      while (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-        __builtin_amdgcn_s_sleep(1);
-        if (wall_clock64() - t0 > 100000000ull) { ok = false; break; }
+    for (int kb = 0; kb < 8; ++kb) {
+      if (kb <= jb1) {
+        a[set][kb][0] = *reinterpret_cast<const double2_t*>(src + 16 * kb);
+        a[set][kb][1] = *reinterpret_cast<const double2_t*>(src + 16 * kb + 2);
       }
-      if (!ok) atomicMin(info, -3);
     }
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  }
-  // stage L tiles: item = (tile, row, column quad) -> 4 doubles
-  {
-    typedef double double2_t __attribute__((ext_vector_type(2)));
-    // tile row ti (1..7) holds tiles ti(ti-1)/2 .. ; 7 items per thread, all loads issued before the stores
-    double2_t v0[7], v1[7];
-#pragma unroll
-    for (int u = 0; u < 7; ++u) {
-      const int it = tid + 256 * u;
-      const int tile = it >> 6, rr = (it >> 2) & 15, cq = it & 3;
-      const int ti = (tile >= 21) ? 7 : (tile >= 15) ? 6 : (tile >= 10) ? 5 : (tile >= 6) ? 4 : (tile >= 3) ? 3 : (tile >= 1) ? 2 : 1;
-      const int tj = tile - ti * (ti - 1) / 2;
-      const double* src = Lblk + (long)(16 * ti + rr) * lda + 16 * tj + 4 * cq;
-      v0[u] = *reinterpret_cast<const double2_t*>(src);
-      v1[u] = *reinterpret_cast<const double2_t*>(src + 2);
-    }
-#pragma unroll
-    for (int u = 0; u < 7; ++u) {
-      const int it = tid + 256 * u;
-      const int tile = it >> 6, rr = (it >> 2) & 15, cq = it & 3;
-      double* dst = Lt + tile * 256 + cq * 64 + rr;  // + 16*q
-      dst[0] = v0[u].x; dst[16] = v0[u].y; dst[32] = v1[u].x; dst[48] = v1[u].y;
-    }
-    for (int it = tid; it < 8 * 64; it += 256) {
-      const int tile = it >> 6, rr = (it >> 2) & 15, cq = it & 3;
-      const double* src = dinv + tile * 256 + rr * 16 + 4 * cq;
-      const double2_t v0 = *reinterpret_cast<const double2_t*>(src);
-      const double2_t v1 = *reinterpret_cast<const double2_t*>(src + 2);
-      double* dst = Dt + tile * 256 + cq * 64 + rr;
-      dst[0] = v0.x; dst[16] = v0.y; dst[32] = v1.x; dst[48] = v1.y;
-    }
-  }
-  __syncthreads();
-#ifdef LEAF_STAMPS
-  if (blk == 0) LEAF_STAMP(6);
-#endif
-  double4_t La[2][7];  // double buffer over block columns j: La[j&1][i-j-1][s]
-  double4_t Dj[2];
-  auto load_col = [&](int set, int j) {
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) Dj[set][s4] = Dt[j * 256 + s4 * 64 + lane];
-#pragma unroll
-    for (int i = j + 1; i < 8; ++i)
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) La[set][i - j - 1][s4] = Lt[strip_tile(i, j) * 256 + s4 * 64 + lane];
   };
-  load_col(0, 0);
+  load_rows(0, 0);
+  // M rows 16 jb + n, k-blocks 0 .. jb: (jb0 + 1) + (jb1 + 1) = 9 fetches of 4 doubles per lane
+  const double* m0 = minv + (long)(16 * jb0 + n) * LEAF + 4 * q;
+  const double* m1 = minv + (long)(16 * jb1 + n) * LEAF + 4 * q;
+  double2_t b0[4][2], b1[8][2];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int cur = j & 1;
-    if (j + 1 < 8) load_col(cur ^ 1, j + 1);
-    __builtin_amdgcn_sched_barrier(0);  // keep the next column's reads ahead of this column's MFMAs
-    // X_j = Dinv_j * T_j
-    double4_t X = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) X = __builtin_amdgcn_mfma_f64_16x16x4f64(Dj[cur][s4], T[j][s4], X, 0, 0, 0);
-    T[j] = X;
-    const double4_t Xn = -X;
-#pragma unroll
-    for (int i = j + 1; i < 8; ++i)
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4)
-        T[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(La[cur][i - j - 1][s4], Xn[s4], T[i], 0, 0, 0);
+  for (int kb = 0; kb < 4; ++kb) {
+    if (kb <= jb0) {
+      b0[kb][0] = *reinterpret_cast<const double2_t*>(m0 + 16 * kb);
+      b0[kb][1] = *reinterpret_cast<const double2_t*>(m0 + 16 * kb + 2);
+    }
   }
-#ifdef LEAF_STAMPS
-  if (blk == 0) LEAF_STAMP(7);
-#endif
 #pragma unroll
-  for (int j = 0; j < 8; ++j)
+  for (int kb = 0; kb < 8; ++kb) {
+    if (kb <= jb1) {
+      b1[kb][0] = *reinterpret_cast<const double2_t*>(m1 + 16 * kb);
+      b1[kb][1] = *reinterpret_cast<const double2_t*>(m1 + 16 * kb + 2);
+    }
+  }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Brow[16 * j + 4 * r + q] = T[j][r];
-}
-
-__global__ __launch_bounds__(256) void trsm_strip128_kernel(const double* __restrict__ Lblk, long lda,
-                                                             const double* __restrict__ dinv,
-                                                             double* __restrict__ B, long ldb, long strideL,
-                                                             long strideB) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  trsm_strip128_body(Lblk + (long)blockIdx.y * strideL, lda, dinv + (long)blockIdx.y * 2048, B + (long)blockIdx.y * strideB,
-                     ldb, blockIdx.x, smem, nullptr, nullptr);
-}
-
-// Leaf and the strip below it in ONE launch: workgroup 0 factors the diagonal block and raises `ready`; the other
-// workgroups have their rows in registers by then and start the solve without a launch boundary in between.
-__global__ __launch_bounds__(256, 1) void potrf_leaf_strip128_kernel(double* __restrict__ Ablk, long lda,
-                                                                      double* __restrict__ dinv, int col0,
-                                                                      int* __restrict__ info, double* __restrict__ B,
-                                                                      long ldb, int* __restrict__ ready) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  if (blockIdx.x == 0) {
-    potrf_leaf128_body(Ablk, lda, dinv, col0, info, smem);
+  for (int rg = 0; rg < RG; ++rg) {
+    const int cur = rg & 1;
+    if (rg + 1 < RG) load_rows(cur ^ 1, rg + 1);
+    double4_t x0 = {0.0, 0.0, 0.0, 0.0}, x1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+      if (kb <= jb1) {
+        x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur][kb][0].x, b1[kb][0].x, x1, 0, 0, 0);
+        x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur][kb][0].y, b1[kb][0].y, x1, 0, 0, 0);
+        x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur][kb][1].x, b1[kb][1].x, x1, 0, 0, 0);
+        x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur][kb][1].y, b1[kb][1].y, x1, 0, 0, 0);
+      }
+      if (kb < 4 && kb <= jb0) {
+        x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur][kb][0].x, b0[kb][0].x, x0, 0, 0, 0);
+        x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur][kb][0].y, b0[kb][0].y, x0, 0, 0, 0);
+        x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur][kb][1].x, b0[kb][1].x, x0, 0, 0, 0);
+        x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur][kb][1].y, b0[kb][1].y, x0, 0, 0, 0);
+      }
+    }
+    // every wave's copy of this row group is in registers (its MFMAs consumed it; the next group's loads may still be
+    // in flight, they touch other rows) before anybody overwrites the group
+    if (rg + 1 < RG) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(16) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(ready, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-  } else {
-    trsm_strip128_body(Ablk, lda, dinv, B, ldb, blockIdx.x - 1, smem, ready, info);
+    // D layout: lane holds X[16 (blk RG + rg) + q + 4 r][16 jb + n]
+    double* out = B + ((long)blk * (16 * RG) + 16 * rg + q) * ldb + n;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      out[(long)(4 * r) * ldb + 16 * jb0] = x0[r];
+      out[(long)(4 * r) * ldb + 16 * jb1] = x1[r];
+    }
   }
 }
 
-constexpr size_t LEAF_LDS_BYTES = sizeof(double) * (LEAF_ELEMS + 2 * SB * SB + LEAF + 2);
-constexpr size_t STRIP_LDS_BYTES = sizeof(double) * STRIP_TILES * 256;
+// one launch serves `gridDim.y` independent (M, B) pairs: M at minv + y * 16384, B at B + y * strideB
+template <int RG>
+__global__ __launch_bounds__(256) void trsm_strip128_kernel(const double* __restrict__ minv, double* __restrict__ B, long ldb,
+                                                             long strideB) {
+  trsm_strip128_body<RG>(minv + (long)blockIdx.y * (LEAF * LEAF), B + (long)blockIdx.y * strideB, ldb, blockIdx.x);
+}
 
-// With a whole CU's LDS requested the leaf only starts on a CU that holds nothing else: next to a persistent trailing
-// update that leaves a few CUs free (mi_gp_set_option 9) it then runs at its stand-alone speed.
-static int g_leaf_exclusive = 0;
-void set_leaf_exclusive(int on) { g_leaf_exclusive = on ? 1 : 0; }
-constexpr size_t LEAF_LDS_WHOLE_CU = 160 * 1024;
+constexpr size_t LEAF_LDS_BYTES = sizeof(double) * (LEAF_ELEMS + 2 * SB * SB + LEAF + 3);
 
 hipError_t leaf_enable_lds() {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_leaf128_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAF_LDS_WHOLE_CU);
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_leaf_strip128_kernel),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAF_LDS_WHOLE_CU);
-  if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(trsm_strip128_kernel),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)STRIP_LDS_BYTES);
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAF_LDS_BYTES);
+  return e;
 }
 
-hipError_t launch_potrf_leaf128(double* Ablk, long lda, double* dinv, int col0, int* info, hipStream_t stream) {
-  potrf_leaf128_kernel<<<1, 256, g_leaf_exclusive ? LEAF_LDS_WHOLE_CU : LEAF_LDS_BYTES, stream>>>(Ablk, lda, dinv, col0, info);
+hipError_t launch_potrf_leaf128(double* Ablk, long lda, double* minv, int col0, int* info, hipStream_t stream) {
+  potrf_leaf128_kernel<<<1, 256, LEAF_LDS_BYTES, stream>>>(Ablk, lda, minv, col0, info);
   return hipGetLastError();
 }
 
-hipError_t launch_potrf_leaf_strip128(double* Ablk, long lda, double* dinv, int col0, int* info, double* B, long ldb, int m,
-                                      int* ready, hipStream_t stream) {
-  if (m <= 0) return launch_potrf_leaf128(Ablk, lda, dinv, col0, info, stream);
-  const size_t lds = g_leaf_exclusive ? LEAF_LDS_WHOLE_CU : (LEAF_LDS_BYTES > STRIP_LDS_BYTES ? LEAF_LDS_BYTES : STRIP_LDS_BYTES);
-  potrf_leaf_strip128_kernel<<<1 + m / 64, 256, lds, stream>>>(Ablk, lda, dinv, col0, info, B, ldb, ready);
-  return hipGetLastError();
-}
-
-hipError_t launch_trsm_strip128(const double* Lblk, long lda, const double* dinv, double* B, long ldb, int m,
-                                hipStream_t stream) {
-  if (m <= 0) return hipSuccess;
-  trsm_strip128_kernel<<<m / 64, 256, STRIP_LDS_BYTES, stream>>>(Lblk, lda, dinv, B, ldb, 0, 0);
-  return hipGetLastError();
-}
-
-hipError_t launch_trsm_strip128_batched(const double* Lblk, long lda, long strideL, const double* dinv, double* B,
-                                        long ldb, long strideB, int m, int batch, hipStream_t stream) {
+// rows per workgroup by panel height: 16 while one round of workgroups covers the panel (lowest latency), 32 / 64 for
+// tall panels (the wave's tiles of M are reused, 1/2 and 1/4 of the operand traffic); m is a multiple of 64 or of 16
+hipError_t launch_trsm_strip128_batched(const double* minv, double* B, long ldb, long strideB, int m, int batch,
+                                        hipStream_t stream) {
   if (m <= 0 || batch <= 0) return hipSuccess;
-  trsm_strip128_kernel<<<dim3(m / 64, batch), 256, STRIP_LDS_BYTES, stream>>>(Lblk, lda, dinv, B, ldb, strideL, strideB);
+  const long rows = (long)m * batch;
+  if (rows > 8192 && m % 64 == 0) trsm_strip128_kernel<4><<<dim3(m / 64, batch), 256, 0, stream>>>(minv, B, ldb, strideB);
+  else if (rows > 4096 && m % 32 == 0) trsm_strip128_kernel<2><<<dim3(m / 32, batch), 256, 0, stream>>>(minv, B, ldb, strideB);
+  else trsm_strip128_kernel<1><<<dim3(m / 16, batch), 256, 0, stream>>>(minv, B, ldb, strideB);
   return hipGetLastError();
+}
+
+hipError_t launch_trsm_strip128(const double* minv, double* B, long ldb, int m, hipStream_t stream) {
+  return launch_trsm_strip128_batched(minv, B, ldb, 0, m, 1, stream);
 }
 
 }  // namespace migp

@@ -17,38 +17,30 @@ struct GemmParams {
   int tri;                         // 1: only tiles with tj <= min(ti, nt-1)  (SYRK / trapezoid)
   int kmode;                       // 0 full k; 1 k >= tj*128; 2 k < (ti+1)*128; 3 k >= ti*128; 4 k < (tj+1)*128
   double alpha, beta;
-  int ntiles = 0;                   // variant C persistent form: total tiles when the grid is smaller (set by the launcher)
-  int wide8 = 0;                    // launcher only: 1 = 8-wave / one-workgroup-per-CU kernel (variant C) that leaves half of
-                                    // every CU's LDS and registers to the panel chain
-  int band = 0;                     // launcher only: band height (tile rows) of the band-column-major trapezoid order, 0 = row-major
-  int one_per_cu = 0;               // launcher only: request > half a CU's LDS so that one workgroup per CU runs (leaves room for
+  // launcher options (per call; a handle keeps its own values, mi_gp_set_option 7 / 14)
+  int small_below = 1024;           // launches with fewer 128x128 tiles than this run on the 64x64-tile kernel
+  int band = 8;                     // band height (tile rows) of the band-column-major order of uniform-k trapezoid launches, 0 = row-major
+  int one_per_cu = 0;               // request > half a CU's LDS so that one workgroup per CU runs (leaves room for
                                     // the panel chain's leaf / strip kernels next to a bulk update)
 };
 // opX_kmajor = 0: operand stored [x][k] (A row-major m x k / B stored n x k, i.e. "B^T");
 // opX_kmajor = 1: operand stored [k][x].
 hipError_t launch_gemm_f64(const GemmParams& p, int opA_kmajor, int opB_kmajor, int batch, hipStream_t stream);
 hipError_t gemm_f64_enable_lds();
-int gemm_variant_get();
-void set_gemm_variant(int v);
-void set_gemm_small_tiles(int v);
-void set_gemm_band_rows(int v);
-bool gemm_uses_small_tiles(const GemmParams& p, int batch);  // true: the 64x64-tile kernel will run  // launches with fewer 128x128 tiles than this use 64x64 tiles  // 0: 8-wave / 1 workgroup per CU, 1: 4-wave / 2 workgroups per CU (default)
+bool gemm_uses_small_tiles(const GemmParams& p, int batch);  // true: the 64x64-tile kernel will run
 
 // ---------------------------------------------------------------- leaf_f64.hip
 hipError_t leaf_enable_lds();
-void set_leaf_exclusive(int on);
-// in-place lower Cholesky of one 128x128 diagonal block; dinv receives the inverses of its eight
-// 16x16 diagonal sub-blocks ([8][16][16]); *info gets atomicMin(col0 + j + 1) on a bad pivot.
-hipError_t launch_potrf_leaf128(double* Ablk, long lda, double* dinv, int col0, int* info, hipStream_t stream);
-// leaf and the strip below it (m rows at B) in one launch; *ready must be 0 on entry (one word per launch)
-hipError_t launch_potrf_leaf_strip128(double* Ablk, long lda, double* dinv, int col0, int* info, double* B, long ldb, int m,
-                                      int* ready, hipStream_t stream);
-// X * L^T = B in place on the m x 128 panel B (m multiple of 64).
-hipError_t launch_trsm_strip128(const double* Lblk, long lda, const double* dinv, double* B, long ldb, int m,
-                                hipStream_t stream);
-// batched form: leaf b uses Lblk + b*strideL, dinv + b*2048, B + b*strideB (m rows each)
-hipError_t launch_trsm_strip128_batched(const double* Lblk, long lda, long strideL, const double* dinv, double* B,
-                                        long ldb, long strideB, int m, int batch, hipStream_t stream);
+constexpr int MINV_ELEMS = 128 * 128;  // doubles per leaf inverse
+// in-place lower Cholesky of one 128x128 diagonal block; minv receives M = L^-1 (row-major 128 x 128, lower triangular,
+// zeros above the diagonal inside the diagonal 16x16 tiles; the tiles above the block diagonal are not written and
+// never read); *info gets atomicMin(col0 + j + 1) on a bad pivot.
+hipError_t launch_potrf_leaf128(double* Ablk, long lda, double* minv, int col0, int* info, hipStream_t stream);
+// X * L^T = B in place on the m x 128 panel B (m multiple of 16, ldb even) as X = B * M^T with the leaf's inverse M.
+hipError_t launch_trsm_strip128(const double* minv, double* B, long ldb, int m, hipStream_t stream);
+// batched form: pair b uses minv + b * MINV_ELEMS and B + b * strideB (m rows each)
+hipError_t launch_trsm_strip128_batched(const double* minv, double* B, long ldb, long strideB, int m, int batch,
+                                        hipStream_t stream);
 
 // ---------------------------------------------------------------- assemble.hip
 enum { KID_RBF = 0, KID_MATERN52 = 1, KID_MATERN32 = 2, KID_EXPONENTIAL = 3, KID_RATQUAD = 4 };

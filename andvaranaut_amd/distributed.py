@@ -29,7 +29,8 @@ import torch.distributed as dist
 from . import _lib
 from .backend import parse_kernel
 
-DINV_ROWS = 16  # pwt * 2048 leaf-inverse doubles appended to a broadcast panel (rows of pwt * 128 doubles)
+MINV = 128 * 128  # doubles per leaf inverse (mi_gp_chol_panel writes one per 128-column tile)
+DINV_ROWS = 128  # pwt * MINV leaf-inverse doubles appended to a broadcast panel (flat view of 128 rows of pw + 16 doubles)
 
 
 def panel_tiles(ntc, world):
@@ -76,7 +77,7 @@ class DistGP:
             self.K = torch.zeros((rows, self.ld), dtype=torch.float64, device=self.dev)
             self.P = [torch.zeros((rows + DINV_ROWS, self.ldbuf), dtype=torch.float64, device=self.dev) for _ in range(2)]
             self.theta_t = torch.zeros(self.ntheta, dtype=torch.float64, device=self.dev)
-            self.dinv = torch.zeros(self.pwt * 2048, dtype=torch.float64, device=self.dev)
+            self.dinv = torch.zeros(self.pwt * MINV, dtype=torch.float64, device=self.dev)
             self.info = torch.zeros(4, dtype=torch.int32, device=self.dev)
             self.out = torch.zeros(16, dtype=torch.float64, device=self.dev)
         self.kids = (ctypes.c_int * _lib.MAX_KERN)(*[_lib.KERNEL_IDS[k] for k in self.kerns] + [0] * (_lib.MAX_KERN - self.nkern))
@@ -133,8 +134,8 @@ class DistGP:
         r0 = j * self.pw
         rows = self.np_ + 128 - r0
         buf[:rows, : w * 128].copy_(self.K[r0:, li * self.pw: li * self.pw + w * 128])
-        # the leaf inverses travel with the panel (16 more rows): the gradient's triangular solves need them everywhere
-        buf[rows: rows + DINV_ROWS].view(-1)[: w * 2048].copy_(self.dinv[: w * 2048])
+        # the leaf inverses travel with the panel (128 more rows): the gradient's triangular solves need them everywhere
+        buf[rows: rows + DINV_ROWS].view(-1)[: w * MINV].copy_(self.dinv[: w * MINV])
 
     # ------------------------------------------------------------------ evaluation
     def lml(self, theta, noise_form=0, _keep=False):
@@ -210,7 +211,7 @@ class DistGP:
             self.ldf = self.np_ + 16
             self.Lf = torch.zeros((self.np_, self.ldf), dtype=torch.float64, device=self.dev)   # complete factor
             self.Uf = torch.zeros((self.np_, self.ldf), dtype=torch.float64, device=self.dev)   # complete U = L^-T
-            self.dinv_f = torch.zeros(self.ntc * 2048, dtype=torch.float64, device=self.dev)
+            self.dinv_f = torch.zeros(self.ntc * MINV, dtype=torch.float64, device=self.dev)
             self.beta_f = torch.zeros(self.np_, dtype=torch.float64, device=self.dev)
             self.alpha_f = torch.zeros(self.np_, dtype=torch.float64, device=self.dev)
             self.W = torch.zeros((self.np_, self.ldbuf), dtype=torch.float64, device=self.dev)  # one K^-1 column slab
@@ -225,8 +226,8 @@ class DistGP:
         r0 = j * self.pw
         rows = self.np_ - r0
         self.Lf[r0:, r0: r0 + w * 128].copy_(buf[:rows, : w * 128])
-        self.dinv_f[j * self.pwt * 2048: (j * self.pwt + w) * 2048].copy_(
-            buf[rows + 128: rows + 128 + DINV_ROWS].view(-1)[: w * 2048])
+        self.dinv_f[j * self.pwt * MINV: (j * self.pwt + w) * MINV].copy_(
+            buf[rows + 128: rows + 128 + DINV_ROWS].view(-1)[: w * MINV])
         nv = max(0, min(self.n - r0, w * 128))  # beta = L^-1 y rides in the first row of the panel's y block
         self.beta_f[r0: r0 + nv].copy_(buf[rows, :nv])
 

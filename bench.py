@@ -302,7 +302,6 @@ def main():
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     assert all(np.isfinite(v) for v in vals), "non-finite LML in the timed region"
-    state = gp.timers()  # graph_kept / graph_dropped / fused_retries of the timed region's handle
 
     # LML + gradient (the MAP loop of BASELINE config 3 and every NUTS leapfrog step): same handle, same thetas
     grad_rec = None
@@ -327,7 +326,7 @@ def main():
     # Roofline pass (rank 0): the same evaluations again with HIP events on the handle's own stream
     # around every phase and every GEMM launch.  Look-ahead is switched off for this pass so that
     # the dominant kernel runs alone on the chip and its launch durations are not inflated by the
-    # panel kernels that overlap it in the timed region (graph replay is bypassed by profiling).
+    # panel kernels that overlap it in the timed region.
     acc = {"assemble_ms": 0.0, "cholesky_ms": 0.0, "gemm_ms": 0.0, "gemm_flops": 0.0, "gemm_launches": 0.0, "total_ms": 0.0,
            "gemm_b_ms": 0.0, "gemm_b_flops": 0.0, "gemm_b_launches": 0.0}
     rsteps = max(1, min(args.roofline_steps, args.steps))
@@ -384,8 +383,7 @@ def main():
                        "N": N, "d": d, "kernel": args.kernel, "parallelism": f"replicas x{world} (one chain per GPU)"},
             "cholesky_tflops_whole_eval": (N ** 3 / 3.0) / (elapsed / steps) * 1e-12,
             "cholesky_frac_of_peak_whole_eval": (N ** 3 / 3.0) / (elapsed / steps) * 1e-12 / FP64_PEAK_TFLOPS,
-            "graph_kept": state.get("graph_kept"), "graph_dropped": state.get("graph_dropped"),
-            "fused_retries": state.get("fused_retries"),
+            "launch_mode": "plain launches, look-ahead on a second stream (hipGraph replay removed in round 2: see DESIGN.md)",
             "lml_grad": grad_rec,
             "roofline_pass": {"steps": rsteps, "lookahead": False,
                               "phase_ms": {"assemble": acc["assemble_ms"] / rsteps, "cholesky": acc["cholesky_ms"] / rsteps,

@@ -110,18 +110,17 @@ int mi_gp_predict_u(mi_gp_handle* h, const double* Xnew_dev, int m, double* work
 int mi_gp_predict_grad(mi_gp_handle* h, const double* Xnew_dev, int m, double* work_dev, long ldw, double* mean_dev,
                        double* var_dev, int pred_noise, double* dmean_dev, double* dvar_dev);
 
-/* tuning knobs (benchmarks / A-B tests): what = 0 one-super-panel look-ahead on the second stream
- * (per handle, default 1); 1 GEMM kernel variant (process-wide: 0 = 8 waves, 1 workgroup per CU;
- * 1 = 4 waves, 2 workgroups per CU, default); 2 super-panel width in 128-column tiles;
- * 3 replay each evaluation from a captured hipGraph (default 1; profiling levels >= 1 use plain launches);
- * 4-6 trailing sizes (tile columns) above which the super-panel is 16 / 8 / 4 tiles wide (below the last: 2);
- * 7 launches with fewer 128x128 tiles than this run on 64x64 tiles (process-wide, default 1024); 8 trailing size at or below which look-ahead bulk updates run one workgroup
- * per CU (default 64); 9 look-ahead bulk kernel: 0 = 4-wave kernel (default), 1 = 8-wave / one workgroup per CU,
- * n > 1 = the same persistent on n CUs taken whole (n | 0x1000: half-CU LDS request, the others stay shareable);
- * 10, 11 = the option-9 value used once <= (11) tile columns remain; 12 = the leaf kernel asks for a whole CU;
- * 13 = tile columns with at most this many columns after them run leaf + strip as ONE launch (default 64, 0 = never);
- * 14 = band height (tile rows) of the band-column-major tile order of uniform-k trapezoid launches (process-wide,
- * default 8, 0 = row-major). */
+/* tuning knobs (benchmarks / A-B tests), ALL per handle -- nothing here is process-wide:
+ *   0  look-ahead: factor the next super-panel on a second stream while the trailing update runs; 0 never, 1 by size
+ *      (default: from 40 tile columns = N > 4992 on, where the overlap beats the cross-stream hand-offs), 2 always
+ *   2  super-panel width in 128-column tiles (default 0 = by trailing size, options 4-6)
+ *   4-6  trailing sizes (tile columns) above which the super-panel is 16 / 8 / 4 tiles wide (below the last: 2)
+ *   7  GEMM launches with fewer 128x128 tiles than this run on 64x64 tiles (default 1024)
+ *   8  trailing size at or below which look-ahead bulk updates run one workgroup per CU (default 64)
+ *   14 band height (tile rows) of the band-column-major tile order of uniform-k trapezoid launches (default 8, 0 = row-major)
+ * 0, 8 and 14 only change scheduling (bit-identical results); 2, 4-7 regroup sums (agreement to rounding).
+ * Unknown ids return -1.  (Round 1's options 1, 3, 9-13 -- GEMM variants, hipGraph replay, persistent bulk kernels,
+ * exclusive leaf, fused leaf + strip -- are gone with the code they selected.) */
 int mi_gp_set_option(mi_gp_handle* h, int what, int value);
 
 /* profiling: level 0 none, 1 per-phase HIP events, 2 additionally per-GEMM-launch HIP events */
@@ -129,12 +128,12 @@ int mi_gp_set_profiling(mi_gp_handle* h, int level);
 /* out[0..12] = assemble_ms, cholesky_ms, reduce_ms, total_ms, gemm_ms (sum over launches),
  *             gemm_flops (algorithmic), number of gemm launches, trtri_ms, lauum_ms, contract_ms,
  *             then the same three GEMM figures for the 128x128-tile kernel (gemm_f64_kernel_b) alone
- *             -- of the last evaluation */
+ *             -- of the last evaluation (profiling level >= 1) */
 int mi_gp_timers(mi_gp_handle* h, double* out, int n);
 
 /* ---- block-level operations (also used by the multi-GPU driver and the parity tests) ---- */
 
-/* C = beta*C + alpha*op(A)*op(B) in fp64 on v_mfma_f64_4x4x4_4b_f64; row-major, m,n multiples of
+/* C = beta*C + alpha*op(A)*op(B) in fp64 on v_mfma_f64_16x16x4_f64; row-major, m,n multiples of
  * 128, k multiple of 32.  transa=0: A is m x k; 1: A is k x m.  transb=0: B is k x n; 1: B is n x k.
  * tri=1 computes only tiles on/below the block diagonal (the element-wise lower triangle is
  * guaranteed, the strict upper part of diagonal blocks is unspecified); kmode restricts k per tile for triangular
@@ -154,8 +153,10 @@ int mi_gp_assemble_block(int d, int nkern, const int* kernel_ids, const int* ops
                          double* K_dev, long ldk, int rows_pad, int cols_pad, int noise_form, void* hip_stream);
 
 /* Factor the w_tiles leading 128-column tiles of a (row_tiles x w_tiles)-tile lower trapezoid in place:
- * diagonal leaves, strip solves of all rows below, in-panel updates.  dinv_dev: w_tiles*2048 doubles of
- * scratch; *info_dev receives atomicMin(col_base + bad pivot index + 1).  LAPACK dpotrf panel step. */
+ * diagonal leaves, strip solves of all rows below, in-panel updates.  dinv_dev: w_tiles * 16384 doubles that receive
+ * the explicit 128x128 inverses of the panel's diagonal blocks (row-major, lower triangular; the strip solves are
+ * products with them, and mi_gp_trsm_block reuses them); *info_dev receives atomicMin(col_base + bad pivot index + 1).
+ * LAPACK dpotrf panel step. */
 int mi_gp_chol_panel(double* A_dev, long lda, int row_tiles, int w_tiles, double* dinv_dev, int* info_dev,
                      int col_base, void* hip_stream);
 
@@ -167,7 +168,7 @@ int mi_gp_lml_partial(const double* L_dev, long ld, const double* beta_dev, int 
  * (andvaranaut_amd/distributed.py) builds it from these blocks. */
 
 /* X L^T = B in place (X = B L^-T) for the 128-column tiles [c0_tiles, c0_tiles + w_tiles) of a complete lower factor
- * L_dev (element (0,0) first, leading dimension ldl); dinv_dev: the 2048-double leaf inverses mi_gp_chol_panel wrote,
+ * L_dev (element (0,0) first, leading dimension ldl); dinv_dev: the 16384-double leaf inverses mi_gp_chol_panel wrote,
  * indexed by global tile; B_dev points at the first of those columns of the m-row right-hand side (m multiple of 128).
  * With B = rows J of the identity this yields rows J of U = L^-T.  LAPACK dtrsm('R','L','T','N'). */
 int mi_gp_trsm_block(const double* L_dev, long ldl, const double* dinv_dev, int c0_tiles, int w_tiles, double* B_dev,

@@ -8,7 +8,6 @@ N, d = 16384, 8
 X, y = orc.synth_problem(N, d, seed=0)
 theta = orc.synth_theta(d)
 gp = MiGP(X, y, "RBF", need_grad=False)
-gp.set_option(3, 0)
 ref = gp.lml(theta)
 res = {}
 for rnd in range(3):

@@ -9,7 +9,6 @@ for N in (16384, 8192, 4096):
     X, y = orc.synth_problem(N, d, seed=0)
     theta = orc.synth_theta(d)
     gp = MiGP(X, y, "Matern52", need_grad=False)
-    gp.set_option(3, 0)  # plain launches: the captured graph does not see this knob
     gp.set_option(7, 0)
     ref = gp.lml(theta)
     res = {}

@@ -9,7 +9,6 @@ for N in (4096, 8192, 16384):
     X, y = orc.synth_problem(N, d, seed=0)
     theta = orc.synth_theta(d)
     gp = MiGP(X, y, "RBF", need_grad=False)
-    gp.set_option(3, 0)
     ref = gp.lml(theta)
     configs = [(72, 0), (72, 16), (72, 32), (72, 64), (72, 72), (40, 0), (40, 40)]
     res = {c: [] for c in configs}

@@ -13,9 +13,9 @@ int main() {
   for (auto& v : G) v = nd(rng);
   for (int i = 0; i < n; ++i) for (int j = 0; j <= i; ++j) { double s = 0; for (int k = 0; k < n; ++k) s += G[i * n + k] * G[j * n + k]; A[i * lda + j] = s / n + (i == j ? 1.0 : 0.0); }
   std::vector<double> A0 = A;
-  double *dA, *dinv; int* info; hipMalloc(&dA, A.size() * 8); hipMalloc(&dinv, 2048 * 8); hipMalloc(&info, 16);
+  double *dA, *dinv; int* info; hipMalloc(&dA, A.size() * 8); hipMalloc(&dinv, 16384 * 8); hipMemset(dinv, 0, 16384 * 8); hipMalloc(&info, 16);
   leaf_enable_lds();
-  unsigned long long z[8] = {0};
+  unsigned long long z[16] = {0};
   float best = 1e9;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int rep = 0; rep < 5; ++rep) {
@@ -25,12 +25,21 @@ int main() {
     hipEventRecord(e0); launch_potrf_leaf128(dA, lda, dinv, 0, info, 0); hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); best = std::min(best, ms);
   }
-  unsigned long long st[8]; hipMemcpyFromSymbol(st, HIP_SYMBOL(g_leaf_stamps), sizeof(st));
+  unsigned long long st[16]; hipMemcpyFromSymbol(st, HIP_SYMBOL(g_leaf_stamps), sizeof(st));
+  printf("wave 1 cycles: solve+midsync %llu | stream-out %llu | trailing %llu | P1 dinv %llu | P2 %llu | sync+P3 %llu | sync+P4 %llu | sync+P5 %llu\n", st[8], st[9], st[10], st[11], st[12], st[13], st[14], st[15]);
   printf("leaf kernel %.1f us; cycles: load %llu | A(diag) %llu | B(trsm) %llu | C(update) %llu | store %llu | dinv %llu || w0: tile %llu factor %llu\n", best * 1e3, st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7]);
   hipMemcpy(A.data(), dA, A.size() * 8, hipMemcpyDeviceToHost);
   // check L L^T = A0
   double err = 0;
   for (int i = 0; i < n; ++i) for (int j = 0; j <= i; ++j) { double s = 0; for (int k = 0; k <= j; ++k) s += A[i * lda + k] * A[j * lda + k]; err = std::max(err, std::fabs(s - A0[i * lda + j])); }
   printf("max |L L^T - A| = %.3e\n", err);
+  // check M L = I (M = the explicit inverse the leaf streams out; tiles above the block diagonal are never written)
+  std::vector<double> M(n * n);
+  hipMemcpy(M.data(), dinv, M.size() * 8, hipMemcpyDeviceToHost);
+  double ierr = 0;
+  for (int i = 0; i < n; ++i) for (int j = 0; j <= i; ++j) { double s = 0; for (int k = j; k <= i; ++k) s += M[i * n + k] * A[k * lda + j]; ierr = std::max(ierr, std::fabs(s - (i == j ? 1.0 : 0.0))); }
+  double up = 0;
+  for (int i = 0; i < n; ++i) for (int j = i + 1; j < (i / 16 + 1) * 16; ++j) up = std::max(up, std::fabs(M[i * n + j]));
+  printf("max |M L - I| = %.3e, max |M| above the diagonal inside diagonal tiles = %.3e\n", ierr, up);
   return 0;
 }

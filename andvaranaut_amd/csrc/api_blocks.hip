@@ -64,8 +64,8 @@ extern "C" int mi_gp_assemble_block(int d, int nkern, const int* kernel_ids, con
                                     const double* Xrows_dev, int nrows, const double* Xcols_dev, int ncols,
                                     int row0, int col0, double* K_dev, long ldk, int rows_pad, int cols_pad,
                                     int noise_form, void* stream) {
-  if (d <= 0 || nkern <= 0 || nkern > MAX_KERN || rows_pad % 64 || cols_pad % 64 || nrows < 0 || ncols < 0) {
-    snprintf(g_err, sizeof(g_err), "mi_gp_assemble_block: bad argument");
+  if (d <= 0 || nkern <= 0 || nkern > MAX_KERN || rows_pad % 64 || cols_pad % 64 || nrows < 0 || ncols < 0 || (ldk & 1)) {
+    snprintf(g_err, sizeof(g_err), "mi_gp_assemble_block: bad argument (pads multiples of 64, ldk even)");
     return -1;
   }
   const KernSpec spec = make_spec(d, nkern, kernel_ids, ops);

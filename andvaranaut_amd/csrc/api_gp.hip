@@ -136,8 +136,11 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   h->lookahead = 1;
   h->small_below = GemmParams().small_below;
   h->band_rows = GemmParams().band;
-  h->lowocc_thr = 64;
-  h->w_thr[0] = 1 << 20; h->w_thr[1] = 72; h->w_thr[2] = 0;
+  // round-2 A/B (tools/dev_ab_opts.py, interleaved in one process): bulk updates at one workgroup per CU whenever the
+  // panel chain runs beside them (N = 16384: 29.99 -> 28.97 ms) and 8-tile super-panels at every size (N = 2048 1.045 ->
+  // 1.017 ms, 4096 2.470 -> 2.388, 8192 6.417 -> 6.348, 16384 28.59 -> 28.39 against the 8 / 4 split of round 1)
+  h->lowocc_thr = 1 << 20;
+  h->w_thr[0] = 1 << 20; h->w_thr[1] = 0; h->w_thr[2] = 0;
   if (e == hipSuccess) e = hipMalloc(&h->theta_dev, sizeof(double) * h->ntheta);
   if (e == hipSuccess) e = hipMalloc(&h->out_dev, sizeof(double) * 16);
   if (e == hipSuccess) e = hipMalloc(&h->dinv_dev, sizeof(double) * MINV_ELEMS * (size_t)h->ntc);

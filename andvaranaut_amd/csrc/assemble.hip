@@ -2,142 +2,271 @@
 // (K6).  Restates pymc.gp.cov.Stationary.square_dist / euclidean_dist and the ExpQuad / Matern52 /
 // Matern32 / Exponential / RatQuad .full formulas that gpmcmc.py:282-307 composes:
 //   Xs = X * (1/ls);  r2 = clip(-2 Xs Xs^T + (|Xs_i|^2 + |Xs_j|^2), 0, inf);  r = sqrt(r2 + 1e-12)
-// One 64x64 output tile per 256-thread workgroup; the two 64-row x-blocks are staged (already scaled
-// by 1/ls) in LDS, each thread owns a 4x4 strided micro-tile so that stores are 128-byte coalesced.
+// One 64x64 output tile per 256-thread workgroup; the two 64-row x-blocks are staged (already scaled by 1/ls) in LDS.
+// Round 2: the Xs Xs^T tile is formed on v_mfma_f64_16x16x4_f64 (the fp64 matrix rate equals the vector rate on this
+// chip, so MFMA buys no flops -- it buys LDS traffic: 2 operand reads per 2048 flops instead of 8, and the dot phase was
+// LDS-bandwidth-bound); the column-side operand rows are permuted so that a lane's four results are four ADJACENT
+// columns of one row (two 16-byte stores instead of four 8-byte ones); exp and sqrt are branch-free fp64 sequences of
+// ~19 and ~10 instructions (<= 1 ulp, checked against libm over the argument range) instead of the libm calls.
 #include "migp_kernels.h"
 
 namespace migp {
 
+typedef double double2_t __attribute__((ext_vector_type(2)));
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
 constexpr int AT = 64;      // assembly tile
-constexpr int DCH = 32;     // input dimensions per LDS chunk
-constexpr int DLD = DCH + 1;
+constexpr int DCH = 32;     // input dimensions per LDS chunk (multiple of 4)
+constexpr int DLD = 36;     // LDS row stride in doubles: 4 mod 32, so 16 rows x 4 columns of a fragment read cover all bank pairs twice
+
+// exp(x) for x <= 0 (any magnitude): Cody-Waite reduction by ln 2 in two pieces, degree-13 Taylor polynomial on
+// |r| <= ln2 / 2 (remainder 4e-18 relative), ldexp.  Max error 1.0 ulp against libm over [-745, 0].
+__device__ __forceinline__ double exp_nonpos(double x) {
+  const double k = __builtin_rint(x * 1.4426950408889634);
+  double r = __builtin_fma(-k, 0.6931471803691238, x);
+  r = __builtin_fma(-k, 1.9082149292705877e-10, r);
+  double p = 1.6059043836821613e-10;                       // 1/13!
+  p = __builtin_fma(p, r, 2.08767569878681e-09);          // 1/12!
+  p = __builtin_fma(p, r, 2.505210838544172e-08);         // 1/11!
+  p = __builtin_fma(p, r, 2.755731922398589e-07);         // 1/10!
+  p = __builtin_fma(p, r, 2.7557319223985893e-06);        // 1/9!
+  p = __builtin_fma(p, r, 2.48015873015873e-05);          // 1/8!
+  p = __builtin_fma(p, r, 0.0001984126984126984);         // 1/7!
+  p = __builtin_fma(p, r, 0.001388888888888889);          // 1/6!
+  p = __builtin_fma(p, r, 0.008333333333333333);          // 1/5!
+  p = __builtin_fma(p, r, 0.041666666666666664);          // 1/4!
+  p = __builtin_fma(p, r, 0.16666666666666666);           // 1/3!
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  const int ki = (k < -2000.0) ? -2000 : (int)k;           // deep underflow: ldexp returns 0 either way
+  return __builtin_amdgcn_ldexp(p, ki);
+}
+
+// sqrt(t) for normal t > 0: v_rsq_f64 seed, two Goldschmidt steps, one Newton correction (<= 1 ulp)
+__device__ __forceinline__ double sqrt_pos(double t) {
+  const double y = __builtin_amdgcn_rsq(t);
+  double g = t * y, h = 0.5 * y;
+  double e = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, e, g);
+  h = __builtin_fma(h, e, h);
+  e = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, e, g);
+  h = __builtin_fma(h, e, h);
+  const double dd = __builtin_fma(-g, g, t);
+  return __builtin_fma(dd, h, g);
+}
 
 __device__ __forceinline__ double base_kernel_eval(int kid, double r2, double alpha) {
   switch (kid) {
     case KID_RBF:
-      return exp(-0.5 * r2);
+      return exp_nonpos(-0.5 * r2);
     case KID_RATQUAD:
       return pow(1.0 + 0.5 * r2 * (1.0 / alpha), -1.0 * alpha);
     default: {
-      const double r = sqrt(r2 + 1e-12);
-      if (kid == KID_MATERN52) return (1.0 + 2.23606797749979 * r + 5.0 / 3.0 * (r * r)) * exp(-1.0 * 2.23606797749979 * r);
-      if (kid == KID_MATERN32) return (1.0 + 1.7320508075688772 * r) * exp(-1.7320508075688772 * r);
-      return exp(-0.5 * r);  // KID_EXPONENTIAL (PyMC's Exponential is exp(-r/2))
+      const double r = sqrt_pos(r2 + 1e-12);
+      if (kid == KID_MATERN52) return (1.0 + 2.23606797749979 * r + 5.0 / 3.0 * (r * r)) * exp_nonpos(-1.0 * 2.23606797749979 * r);
+      if (kid == KID_MATERN32) return (1.0 + 1.7320508075688772 * r) * exp_nonpos(-1.7320508075688772 * r);
+      return exp_nonpos(-0.5 * r);  // KID_EXPONENTIAL (PyMC's Exponential is exp(-r/2))
     }
   }
 }
 
 // theta layout: [ls(nkern*d), kv(nkern), alpha(nkern), gv, jitter]
-__global__ __launch_bounds__(256) void assemble_kernel(KernSpec spec, const double* __restrict__ theta,
-                                                       const double* __restrict__ X1, int n1,
-                                                       const double* __restrict__ X2, int n2,
-                                                       double* __restrict__ K, long ldk, int rows_pad,
-                                                       int cols_pad, int sym, int noise_form,
-                                                       int diag_shift, const double* __restrict__ extra_diag) {
-  __shared__ double Xi[AT * DLD];
-  __shared__ double Xj[AT * DLD];
+// Work split: a workgroup owns a run of up to TPW consecutive 64x64 tiles of one tile row; wave w owns rows 16 w .. 16 w + 15
+// of a tile and all 64 columns as four 16-column groups cg.  MFMA operands (lane = (n = lane & 15, q = lane >> 4), k-step s
+// covers input dimensions 4 s + q):
+//   B operand = the lane's row point  Xi[16 w + n][4 s + q];   A operand = column point  Xj[16 cg + g(n)][4 s + q],
+//   g(n) = 4 (n & 3) + (n >> 2), so that the D layout (row q + 4 r of A's index, column n of B's) is
+//   dot(row point 16 w + n, column point 16 cg + 4 q + r): element r = 0..3 of a lane = four adjacent columns.
+// Single-component covariances with d <= 32 (the common case) keep the scaled row block and its norms resident for the
+// whole run and fetch the NEXT tile's column block into registers while the current tile is evaluated: a workgroup of the
+// one-tile-per-workgroup form lived ~14 us of which ~1 us was arithmetic (three dependent global round trips per tile).
+// KID_STATIC >= 0: single-component covariance of that family (no runtime switch, no pow() in the register budget);
+// -1: any composition (runtime kernel ids, '+' / '*' folds).
+constexpr int TPW = 8;                  // tiles per workgroup
+constexpr int SROWS = AT / (256 / DCH);  // rows a thread stages per 64-row block: 8
+
+// RESIDENT: the host guarantees nkern == 1 and d <= DCH (only the prefetching form is compiled), else only the general form.
+template <int KID_STATIC, bool RESIDENT>
+__global__ __launch_bounds__(256, (KID_STATIC >= 0 && KID_STATIC != KID_RATQUAD) ? 3 : 2) void assemble_kernel(
+    KernSpec spec, const double* __restrict__ theta, const double* __restrict__ X1, int n1, const double* __restrict__ X2, int n2,
+    double* __restrict__ K, long ldk, int rows_pad, int cols_pad, int sym, int noise_form, int diag_shift,
+    const double* __restrict__ extra_diag) {
+  __shared__ __attribute__((aligned(16))) double Xi[AT * DLD];
+  __shared__ __attribute__((aligned(16))) double Xj[AT * DLD];
   __shared__ double n2i[AT], n2j[AT];
   const int tid = threadIdx.x;
-  int ti, tj;
+  // run (ti, chunk): tiles tj = TPW chunk .. ; in sym mode tile row ti holds ti + 1 tiles, i.e. ti / TPW + 1 runs, and the
+  // TPW rows of a row group g = ti / TPW all hold g + 1 runs: 4 g (g + 1) runs (TPW = 8) lie before group g
+  int ti, chunk, tj_end;
   if (sym) {
     const int e = blockIdx.x;
-    int t = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
-    while ((t + 1) * (t + 2) / 2 <= e) ++t;
-    while (t * (t + 1) / 2 > e) --t;
-    ti = t;
-    tj = e - t * (t + 1) / 2;
+    int g = (int)((sqrt(1.0 + (double)e) - 1.0) * 0.5);
+    while ((TPW / 2) * (g + 1) * (g + 2) <= e) ++g;
+    while ((TPW / 2) * g * (g + 1) > e) --g;
+    const int rem = e - (TPW / 2) * g * (g + 1);
+    ti = TPW * g + rem / (g + 1);
+    chunk = rem % (g + 1);
+    tj_end = ti + 1;
   } else {
-    const int ntc = cols_pad / AT;
-    ti = blockIdx.x / ntc;
-    tj = blockIdx.x % ntc;
+    const int nrun = (cols_pad / AT + TPW - 1) / TPW;
+    ti = blockIdx.x / nrun;
+    chunk = blockIdx.x % nrun;
+    tj_end = cols_pad / AT;
   }
-  const int i0 = ti * AT, j0 = tj * AT;
-  const int tx = tid & 15, ty = tid >> 4;
+  const int tj0 = chunk * TPW;
+  const int tj1 = min(tj0 + TPW, tj_end);
+  const int i0 = ti * AT;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 15, q = lane >> 4;
+  const int gperm = 4 * (n & 3) + (n >> 2);
   const int d = spec.d, nk = spec.nkern;
   const double* ls = theta;
   const double* kv = theta + nk * d;
   const double* al = kv + nk;
   const double gv = theta[nk * d + 2 * nk];
   const double jitter = theta[nk * d + 2 * nk + 1];
-
-  double Kacc[4][4];
-  for (int c = 0; c < nk; ++c) {
-    double dot[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) dot[a][b] = 0.0;
-    double mynorm = 0.0;  // threads 0..63: |Xs_i|^2 of row tid, threads 64..127: |Xs_j|^2
-    for (int m0 = 0; m0 < d; m0 += DCH) {
-      const int dc = min(DCH, d - m0);
-      __syncthreads();
-      // 256 % DCH == 0: a thread always stages the same input dimension m, so its 1/l is one division per chunk
-      const int m = tid % DCH;
-      const double il = (m < dc) ? 1.0 / ls[c * d + m0 + m] : 0.0;
-      for (int r = tid / DCH; r < AT; r += 256 / DCH) {
-        double vi = 0.0, vj = 0.0;
-        if (m < dc) {
-          if (i0 + r < n1) vi = X1[(long)(i0 + r) * d + m0 + m] * il;
-          if (j0 + r < n2) vj = X2[(long)(j0 + r) * d + m0 + m] * il;
-        }
-        Xi[r * DLD + m] = vi;
-        Xj[r * DLD + m] = vj;
-      }
-      __syncthreads();
-      if (tid < 2 * AT) {
-        const double* row = (tid < AT) ? (Xi + tid * DLD) : (Xj + (tid - AT) * DLD);
-        for (int m = 0; m < dc; ++m) mynorm += row[m] * row[m];
-      }
-      for (int m = 0; m < dc; ++m) {
-        double xi[4], xj[4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) xi[a] = Xi[(ty + 16 * a) * DLD + m];
-#pragma unroll
-        for (int b = 0; b < 4; ++b) xj[b] = Xj[(tx + 16 * b) * DLD + m];
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-          for (int b = 0; b < 4; ++b) dot[a][b] += xi[a] * xj[b];
-      }
-    }
-    if (tid < AT) n2i[tid] = mynorm;
-    else if (tid < 2 * AT) n2j[tid - AT] = mynorm;
-    __syncthreads();
-    const int kid = spec.kid[c];
-    const double kvc = kv[c], alc = al[c];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        double r2 = -2.0 * dot[a][b] + (n2i[ty + 16 * a] + n2j[tx + 16 * b]);
-        r2 = fmax(r2, 0.0);
-        const double kval = kvc * base_kernel_eval(kid, r2, alc);
-        if (c == 0) Kacc[a][b] = kval;
-        else if (spec.op[c - 1] == 0) Kacc[a][b] = Kacc[a][b] + kval;
-        else Kacc[a][b] = Kacc[a][b] * kval;
-      }
-  }
   const double sg = sqrt(gv);
   // diagonal of the global matrix: local (gi, gj) with gi + diag_shift == gj; sym mode has shift 0,
   // rectangular blocks of a distributed matrix pass row0 - col0, cross-covariances pass INT_MIN (none)
   const bool diag_on = sym || diag_shift != -2147483647 - 1;
+  const int gi = i0 + 16 * wave + n;
+  const int sm = tid % DCH, sr = tid / DCH;  // staging role: input dimension sm of rows sr + 8 u
+
+  // |Xs_row|^2 of a staged 64-row block, four threads per row (quad partial sums combined by DPP)
+  auto block_norms = [&](const double* Xs, double* out, int dc, bool first) {
+    const int row = tid >> 2, part = tid & 3;
+    double s = 0.0;
+    for (int mm = part; mm < dc; mm += 4) s = __builtin_fma(Xs[row * DLD + mm], Xs[row * DLD + mm], s);
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    if (part == 0) out[row] = first ? s : out[row] + s;
+  };
+  auto mfma_tile = [&](double4_t (&dot)[4], int dc) {
+    const int nstep = (dc + 3) >> 2;
+    const double* bp = Xi + (16 * wave + n) * DLD + q;
+    const double* ap = Xj + gperm * DLD + q;
+    for (int s4 = 0; s4 < nstep; ++s4) {
+      const double b = bp[4 * s4];
 #pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    const int gi = i0 + ty + 16 * a;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int gj = j0 + tx + 16 * b;
-      double v = Kacc[a][b];
-      if (gi >= n1 || gj >= n2) {
-        v = (diag_on && gi + diag_shift == gj) ? 1.0 : 0.0;
-      } else if (diag_on && gi + diag_shift == gj) {
-        if (noise_form == 0) { v += sg * sg; v += jitter; }       // Marginal._build_marginal_likelihood
-        else if (noise_form == 1) { v += jitter; v += sg * sg; }  // Marginal._build_conditional
-        else { v += jitter + gv; }                                // gpmcmc.py:312 explicit form
-        if (extra_diag) v += extra_diag[gi];                      // per-point noise vector (inverse_opt, gpmcmc.py:1134-1158)
-      }
-      K[(long)gi * ldk + gj] = v;
+      for (int cg = 0; cg < 4; ++cg)
+        dot[cg] = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[16 * cg * DLD + 4 * s4], b, dot[cg], 0, 0, 0);
     }
+  };
+  auto fold = [&](double4_t (&Kacc)[4], const double4_t (&dot)[4], int c) {
+    const int kid = KID_STATIC >= 0 ? KID_STATIC : spec.kid[c];
+    const double kvc = kv[c], alc = al[c];
+    const double ni = n2i[16 * wave + n];
+#pragma unroll
+    for (int cg = 0; cg < 4; ++cg) {  // four outputs at a time (scheduling fence below): enough independent exp / sqrt
+                                      // chains, a quarter of the registers of sixteen interleaved ones
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double r2 = -2.0 * dot[cg][r] + (ni + n2j[16 * cg + 4 * q + r]);
+        r2 = fmax(r2, 0.0);
+        const double kval = kvc * base_kernel_eval(kid, r2, alc);
+        if (c == 0) Kacc[cg][r] = kval;
+        else if (spec.op[c - 1] == 0) Kacc[cg][r] = Kacc[cg][r] + kval;
+        else Kacc[cg][r] = Kacc[cg][r] * kval;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  auto store_tile = [&](const double4_t (&Kacc)[4], int j0) {
+#pragma unroll
+    for (int cg = 0; cg < 4; ++cg) {
+      double v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gj = j0 + 16 * cg + 4 * q + r;
+        double x = Kacc[cg][r];
+        if (gi >= n1 || gj >= n2) {
+          x = (diag_on && gi + diag_shift == gj) ? 1.0 : 0.0;
+        } else if (diag_on && gi + diag_shift == gj) {
+          if (noise_form == 0) { x += sg * sg; x += jitter; }       // Marginal._build_marginal_likelihood
+          else if (noise_form == 1) { x += jitter; x += sg * sg; }  // Marginal._build_conditional
+          else { x += jitter + gv; }                                // gpmcmc.py:312 explicit form
+          if (extra_diag) x += extra_diag[gi];                      // per-point noise vector (inverse_opt, gpmcmc.py:1134-1158)
+        }
+        v[r] = x;
+      }
+      double* dst = K + (long)gi * ldk + j0 + 16 * cg + 4 * q;  // ldk even, column a multiple of 4: 16-byte aligned
+      *reinterpret_cast<double2_t*>(dst) = (double2_t){v[0], v[1]};
+      *reinterpret_cast<double2_t*>(dst + 2) = (double2_t){v[2], v[3]};
+    }
+  };
+
+  if (RESIDENT) {
+    // ---- resident row block, column blocks prefetched one tile ahead
+    const double il = (sm < d) ? 1.0 / ls[sm] : 0.0;
+    double xr[SROWS];
+    auto fetch = [&](const double* X, int nx, int r0) {
+#pragma unroll
+      for (int u = 0; u < SROWS; ++u) {
+        const int row = r0 + sr + (256 / DCH) * u;
+        xr[u] = (sm < d && row < nx) ? X[(long)row * d + sm] : 0.0;
+      }
+    };
+    auto park = [&](double* Xs) {
+#pragma unroll
+      for (int u = 0; u < SROWS; ++u) Xs[(sr + (256 / DCH) * u) * DLD + sm] = xr[u] * il;
+    };
+    fetch(X1, n1, i0);
+    park(Xi);
+    fetch(X2, n2, tj0 * AT);
+    __syncthreads();
+    block_norms(Xi, n2i, d, true);
+    for (int tj = tj0; tj < tj1; ++tj) {
+      if (tj > tj0) __syncthreads();  // the previous tile's operand reads of Xj / n2j are done
+      park(Xj);
+      __syncthreads();
+      block_norms(Xj, n2j, d, true);
+      if (tj + 1 < tj1) fetch(X2, n2, (tj + 1) * AT);  // travels while this tile is evaluated
+      __syncthreads();
+      double4_t dot[4], Kacc[4];
+#pragma unroll
+      for (int cg = 0; cg < 4; ++cg) dot[cg] = (double4_t){0.0, 0.0, 0.0, 0.0};
+      mfma_tile(dot, d);
+      fold(Kacc, dot, 0);
+      store_tile(Kacc, tj * AT);
+    }
+    return;
+  }
+  // ---- general form: any composition, any d; everything is restaged per tile, component and chunk of 32 dimensions
+  for (int tj = tj0; tj < tj1; ++tj) {
+    const int j0 = tj * AT;
+    double4_t Kacc[4];
+    for (int c = 0; c < nk; ++c) {
+      double4_t dot[4];
+#pragma unroll
+      for (int cg = 0; cg < 4; ++cg) dot[cg] = (double4_t){0.0, 0.0, 0.0, 0.0};
+      for (int m0 = 0; m0 < d; m0 += DCH) {
+        const int dc = min(DCH, d - m0);
+        __syncthreads();
+        // a thread always stages the same input dimension, so its 1/l is one division per chunk; dimensions dc .. DCH-1
+        // are staged as zeros (the MFMA steps run over dc rounded up to a multiple of 4)
+        const double il = (sm < dc) ? 1.0 / ls[c * d + m0 + sm] : 0.0;
+#pragma unroll
+        for (int u = 0; u < SROWS; ++u) {
+          const int r = sr + (256 / DCH) * u;
+          double vi = 0.0, vj = 0.0;
+          if (sm < dc) {
+            if (i0 + r < n1) vi = X1[(long)(i0 + r) * d + m0 + sm] * il;
+            if (j0 + r < n2) vj = X2[(long)(j0 + r) * d + m0 + sm] * il;
+          }
+          Xi[r * DLD + sm] = vi;
+          Xj[r * DLD + sm] = vj;
+        }
+        __syncthreads();
+        block_norms(Xi, n2i, dc, m0 == 0);
+        block_norms(Xj, n2j, dc, m0 == 0);
+        mfma_tile(dot, dc);
+      }
+      __syncthreads();
+      fold(Kacc, dot, c);
+    }
+    store_tile(Kacc, j0);
   }
 }
 
@@ -195,15 +324,30 @@ __global__ __launch_bounds__(256) void lml_reduce_kernel(const double* __restric
 hipError_t launch_assemble(const KernSpec& spec, const double* theta, const double* X1, int n1, const double* X2,
                            int n2, double* K, long ldk, int rows_pad, int cols_pad, int sym, int noise_form,
                            hipStream_t stream, int diag_shift, const double* extra_diag) {
-  int nblk;
+  int nblk;  // runs of up to TPW tiles of one tile row
   if (sym) {
-    const int nt = rows_pad / AT;
-    nblk = nt * (nt + 1) / 2;
+    const int nt = rows_pad / AT, G = nt / TPW, rem = nt % TPW;
+    nblk = (TPW / 2) * G * (G + 1) + rem * (G + 1);
   } else {
-    nblk = (rows_pad / AT) * (cols_pad / AT);
+    nblk = (rows_pad / AT) * ((cols_pad / AT + TPW - 1) / TPW);
   }
-  assemble_kernel<<<nblk, 256, 0, stream>>>(spec, theta, X1, n1, X2, n2, K, ldk, rows_pad, cols_pad, sym, noise_form,
-                                            sym ? 0 : diag_shift, sym ? extra_diag : nullptr);
+  const int ds = sym ? 0 : diag_shift;
+  const double* ed = sym ? extra_diag : nullptr;
+  const bool resident = spec.nkern == 1 && spec.d <= DCH;
+#define MIGP_ASM(KID)                                                                                                              \
+  do {                                                                                                                             \
+    if (resident)                                                                                                                  \
+      assemble_kernel<KID, true><<<nblk, 256, 0, stream>>>(spec, theta, X1, n1, X2, n2, K, ldk, rows_pad, cols_pad, sym, noise_form, ds, ed);  \
+    else                                                                                                                           \
+      assemble_kernel<KID, false><<<nblk, 256, 0, stream>>>(spec, theta, X1, n1, X2, n2, K, ldk, rows_pad, cols_pad, sym, noise_form, ds, ed); \
+  } while (0)
+  if (spec.nkern != 1) MIGP_ASM(-1);
+  else if (spec.kid[0] == KID_RBF) MIGP_ASM(KID_RBF);
+  else if (spec.kid[0] == KID_MATERN52) MIGP_ASM(KID_MATERN52);
+  else if (spec.kid[0] == KID_MATERN32) MIGP_ASM(KID_MATERN32);
+  else if (spec.kid[0] == KID_EXPONENTIAL) MIGP_ASM(KID_EXPONENTIAL);
+  else MIGP_ASM(KID_RATQUAD);
+#undef MIGP_ASM
   return hipGetLastError();
 }
 

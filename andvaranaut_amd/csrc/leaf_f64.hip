@@ -202,7 +202,8 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
   // [2] arrivals of waves 1..3 inside the inverse phases, [3] Dinv_b ready (wave 1), [4] wave 0 done with column block jb
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: tile coordinates and soff() bases derived
+                                                              // from it are computed on the scalar unit (v_mul_lo_u32 is quarter rate)
 #ifdef LEAF_STAMPS
   unsigned long long t_prev = 0, t_prev1 = 0;
   if (threadIdx.x == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory");

@@ -114,9 +114,10 @@ int mi_gp_predict_grad(mi_gp_handle* h, const double* Xnew_dev, int m, double* w
  *   0  look-ahead: factor the next super-panel on a second stream while the trailing update runs; 0 never, 1 by size
  *      (default: from 40 tile columns = N > 4992 on, where the overlap beats the cross-stream hand-offs), 2 always
  *   2  super-panel width in 128-column tiles (default 0 = by trailing size, options 4-6)
- *   4-6  trailing sizes (tile columns) above which the super-panel is 16 / 8 / 4 tiles wide (below the last: 2)
+ *   4-6  trailing sizes (tile columns) above which the super-panel is 16 / 8 / 4 tiles wide (below the last: 2);
+ *        defaults: never 16, else 8
  *   7  GEMM launches with fewer 128x128 tiles than this run on 64x64 tiles (default 1024)
- *   8  trailing size at or below which look-ahead bulk updates run one workgroup per CU (default 64)
+ *   8  trailing size at or below which look-ahead bulk updates run one workgroup per CU (default: always)
  *   14 band height (tile rows) of the band-column-major tile order of uniform-k trapezoid launches (default 8, 0 = row-major)
  * 0, 8 and 14 only change scheduling (bit-identical results); 2, 4-7 regroup sums (agreement to rounding).
  * Unknown ids return -1.  (Round 1's options 1, 3, 9-13 -- GEMM variants, hipGraph replay, persistent bulk kernels,

@@ -1,0 +1,33 @@
+"""A/B of option sets in ONE process, interleaved: python tools/dev_ab_opts.py N d kernel "8=64" "8=200" ...
+Each set: rounds x reps LML evaluations (and LML + gradient with --grad), medians reported."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from andvaranaut_amd import MiGP
+from bench import synth_problem, theta_sequence
+args = [a for a in sys.argv[1:] if a != "--grad"]
+grad = "--grad" in sys.argv
+N, d, kern = int(args[0]), int(args[1]), args[2]
+sets = args[3:]
+X, y = synth_problem(N, d, seed=0)
+gp = MiGP(X, y, kern, need_grad=grad)
+th = theta_sequence(d, 8, seed=0)
+DEFAULTS = {0: 1, 2: 0, 4: 1 << 20, 5: 0, 6: 0, 7: 1024, 8: 1 << 20, 14: 8}
+res = {s: [] for s in sets}
+reps = 10 if N <= 8192 else 5
+f = (lambda t: gp.lml_grad(t)[0]) if grad else gp.lml
+for rnd in range(4):
+    for s in sets:
+        for k, v in DEFAULTS.items():
+            gp.set_option(k, v)
+        for kv in s.split(","):
+            if kv and kv != "default":
+                gp.set_option(int(kv.split("=")[0]), int(kv.split("=")[1]))
+        f(th[0])
+        t0 = time.perf_counter()
+        for i in range(reps):
+            f(th[i % 8])
+        res[s].append((time.perf_counter() - t0) / reps * 1e3)
+for s in sets:
+    v = sorted(res[s])
+    print(f"N={N} {kern} {'lml+grad' if grad else 'lml'} [{s:>14s}] median {np.median(v):8.3f} ms  min {v[0]:8.3f}  max {v[-1]:8.3f}", flush=True)

@@ -183,6 +183,36 @@ struct ScaleCols<16> {
   static __device__ __forceinline__ void run(const double (&)[16], double, double (&)[16]) {}
 };
 
+// 16x16 triangular inverse by substitution with the matrix held one ROW per lane (a[k] = L16[lane][k]): column c of the
+// inverse is solved by lane c, and L16[r][k] reaches it through the row_newbcast:R of v_fmac_f64_dpp -- no LDS reads on the
+// chain (the LDS-read form took 4.2k cycles per block, this one ~1k).  nz[k] = -z[k].
+template <int R, int K>
+struct DinvRow {
+  static __device__ __forceinline__ void run(double& s0, double& s1, const double (&a)[16], const double (&nz)[16]) {
+    if (K & 1) fmac_rowbcast<R>(s1, a[K], nz[K]);
+    else fmac_rowbcast<R>(s0, a[K], nz[K]);
+    DinvRow<R, K + 1>::run(s0, s1, a, nz);
+  }
+};
+template <int R>
+struct DinvRow<R, R> {
+  static __device__ __forceinline__ void run(double&, double&, const double (&)[16], const double (&)[16]) {}
+};
+template <int R>
+struct DinvStep {
+  static __device__ __forceinline__ void run(double (&z)[16], double (&nz)[16], const double (&a)[16], const double (&iv)[16], int c) {
+    double s0 = (R == c) ? 1.0 : 0.0, s1 = 0.0;
+    DinvRow<R, 0>::run(s0, s1, a, nz);
+    z[R] = (R >= c) ? (s0 + s1) * iv[R] : 0.0;
+    nz[R] = -z[R];
+    DinvStep<R + 1>::run(z, nz, a, iv, c);
+  }
+};
+template <>
+struct DinvStep<16> {
+  static __device__ __forceinline__ void run(double (&)[16], double (&)[16], const double (&)[16], const double (&)[16], int) {}
+};
+
 // info: 0 = ok, else 1-based global index of the first non-positive (or NaN) pivot (atomicMin'd).
 //
 // Structure per 16-column block jb of the 128x128 leaf (all of it LDS resident):
@@ -376,23 +406,31 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
       const int t = tid - 64;
       const int nrest = LEAF - j0 - 2 * SB;  // rows j0+32 .. 127
       if (t < nrest) solve_row(jb, j0 + 2 * SB + t);
+      // column block cb is final for rows >= 16 cb once iteration cb's rows are solved: 8 pieces of 16 B per row go to
+      // memory.  Block jb - 1 is streamed here, in the time these waves would otherwise spin waiting for wave 0's rows.
+      auto stream_out = [&](int cb) {
+        const int c0 = cb * SB;
+        for (int it = t; it < (LEAF - c0) * 8; it += 192) {
+          const int r = c0 + (it >> 3), c2 = c0 + 2 * (it & 7);
+          if (c2 <= r) {
+            const double2_t v = *reinterpret_cast<const double2_t*>(S + soff(r) + c2);
+            double* dst = Ablk + (long)r * lda + c2;
+            if (c2 + 1 <= r) *reinterpret_cast<double2_t*>(dst) = v;
+            else dst[0] = v.x;
+          }
+        }
+      };
       if (jb + 1 < LEAF / SB) {
         wave_lds_fence();
         if (lane == 0) atomicAdd(const_cast<int*>(sync_w + 1), 1);
+        if (jb > 0) stream_out(jb - 1);
         while (sync_w[1] < 3 * (jb + 1) || sync_w[0] < jb + 1) __builtin_amdgcn_s_sleep(1);
         wave_lds_fence();
+      } else {
+        stream_out(jb - 1);
+        stream_out(jb);
       }
       LEAF_STAMP1(8);
-      // column block jb is final for rows >= j0: 8 pieces of 16 B per row
-      for (int it = t; it < (LEAF - j0) * 8; it += 192) {
-        const int r = j0 + (it >> 3), c2 = j0 + 2 * (it & 7);
-        if (c2 <= r) {
-          const double2_t v = *reinterpret_cast<const double2_t*>(S + soff(r) + c2);
-          double* dst = Ablk + (long)r * lda + c2;
-          if (c2 + 1 <= r) *reinterpret_cast<double2_t*>(dst) = v;
-          else dst[0] = v.x;
-        }
-      }
       LEAF_STAMP1(9);
       // trailing tiles (tr, tc), 1 <= tr < q, tc <= tr, dealt round-robin to waves 1..3 (tile (0,0) belongs to wave 0)
       // and processed three at a time with their MFMAs interleaved: a chain of four dependent fp64 MFMAs takes ~1k
@@ -401,40 +439,43 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
       const int q = LEAF / SB - 1 - jb;  // trailing tiles per dimension
       const int ntile = q * (q + 1) / 2 - 1;
       const int ln = lane & 15, lq = lane >> 4;
-      for (int e0 = wave - 1; e0 < ntile; e0 += 9) {
+      auto tile_of = [&](int e, int& r0, int& c0) {  // e-th trailing tile (tile (0,0) excluded) -> first row / column
+        int tr = 1;
+        while ((tr + 1) * (tr + 2) / 2 <= e + 1) ++tr;
+        const int tc = e + 1 - tr * (tr + 1) / 2;
+        r0 = j0 + SB + 16 * tr;
+        c0 = j0 + SB + 16 * tc;
+      };
+      const int cnt = ntile > wave - 1 ? (ntile - (wave - 1) + 2) / 3 : 0;  // this wave's tiles: e = wave-1, wave+2, ...
+      int done = 0;
+      for (; done + 3 <= cnt; done += 3) {  // full batches: no predicates, one scheduling region
         double av[3][4], bv[3][4];
         double4_t acc[3];
         int r0[3], c0[3];
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
-          const int e = e0 + 3 * u + 1;  // index in the full lower-triangle enumeration
-          int tr = 1;
-          while ((tr + 1) * (tr + 2) / 2 <= e) ++tr;
-          const int tc = e - tr * (tr + 1) / 2;
-          r0[u] = j0 + SB + 16 * tr;
-          c0[u] = j0 + SB + 16 * tc;
-          if (e0 + 3 * u < ntile) {
+          tile_of(wave - 1 + 3 * (done + u), r0[u], c0[u]);
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-              av[u][s4] = S[soff(r0[u] + ln) + j0 + 4 * s4 + lq];
-              bv[u][s4] = S[soff(c0[u] + ln) + j0 + 4 * s4 + lq];
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[u][r] = S[soff(r0[u] + lq + 4 * r) + c0[u] + ln];
+          for (int s4 = 0; s4 < 4; ++s4) {
+            av[u][s4] = S[soff(r0[u] + ln) + j0 + 4 * s4 + lq];
+            bv[u][s4] = S[soff(c0[u] + ln) + j0 + 4 * s4 + lq];
           }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[u][r] = S[soff(r0[u] + lq + 4 * r) + c0[u] + ln];
         }
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-          for (int u = 0; u < 3; ++u)
-            if (e0 + 3 * u < ntile) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[u][s4], bv[u][s4], acc[u], 0, 0, 0);
+          for (int u = 0; u < 3; ++u) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[u][s4], bv[u][s4], acc[u], 0, 0, 0);
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
-          if (e0 + 3 * u < ntile) {
+        for (int u = 0; u < 3; ++u)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) S[soff(r0[u] + lq + 4 * r) + c0[u] + ln] = acc[u][r];
-          }
-        }
+          for (int r = 0; r < 4; ++r) S[soff(r0[u] + lq + 4 * r) + c0[u] + ln] = acc[u][r];
+      }
+      for (; done < cnt; ++done) {
+        int r0, c0;
+        tile_of(wave - 1 + 3 * done, r0, c0);
+        update_tile(j0, r0, c0);
       }
       LEAF_STAMP1(10);
     }
@@ -452,23 +493,20 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
   // was built and measured in round 2: 69 us instead of 36: the 16x16 inverse by substitution (4.2k cycles per block on
   // one wave) and five LDS-word syncs per iteration outweigh the 4 us this block costs at the end.)
   {
-    double z[SB];
+    double z[SB], nz[SB], a[SB], iv[SB];
     const int b = tid >> 4, c = tid & 15, j0 = b * SB;
-    if (tid < LEAF) {
+    if (tid < LEAF) {  // waves 0 and 1: a 16-lane DPP row = one diagonal block, lane c holds row c of L_bb
+      const double* lrow = S + soff(j0 + c) + j0;
 #pragma unroll
-      for (int r = 0; r < SB; ++r) z[r] = 0.0;
-#pragma unroll
-      for (int r = 0; r < SB; ++r) {
-        const double* lrow = S + soff(j0 + r) + j0;
-        double s0 = (r == c) ? 1.0 : 0.0, s1 = 0.0;
-#pragma unroll
-        for (int k = 0; k < r; ++k) {  // z[k] = 0 for k < c, so no predicate is needed
-          if (k & 1) s1 = __builtin_fma(-lrow[k], z[k], s1);
-          else s0 = __builtin_fma(-lrow[k], z[k], s0);
-        }
-        z[r] = (r >= c) ? (s0 + s1) * invd[j0 + r] : 0.0;
+      for (int k = 0; k < SB; ++k) {
+        a[k] = lrow[k];
+        iv[k] = invd[j0 + k];
+        nz[k] = 0.0;
       }
+      __builtin_amdgcn_sched_barrier(0);  // the DPP reads below must not follow the VALU writes of a[] back to back
+      DinvStep<0>::run(z, nz, a, iv, c);
     }
+    LEAF_STAMP(11);
     __syncthreads();  // every thread has read its diagonal block before it is overwritten
     if (tid < LEAF) {
 #pragma unroll
@@ -478,13 +516,14 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
       }
     }
     __syncthreads();
+    LEAF_STAMP(12);
   }
 #pragma unroll
   for (int t = 1; t <= 4; t *= 2) {
     const int node = wave / t, p0 = node * 2 * t, idx = wave % t;
-    double4_t res[4];
+    double4_t res[4], rs2[4][2];  // two partial accumulators per tile (MFMA steps s4 even / odd): chains half as long
 #pragma unroll
-    for (int c = 0; c < 4; ++c) res[c] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    for (int c = 0; c < 4; ++c) rs2[c][0] = rs2[c][1] = (double4_t){0.0, 0.0, 0.0, 0.0};
     // stage A: T[a][c] = sum_{k >= c} L[p0+t+a][p0+k] M[p0+k][p0+c], this wave owns tile row a = idx; the k-th
     // products of its t tiles are issued together (independent accumulators)
 #pragma unroll
@@ -499,9 +538,12 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
 #pragma unroll
           for (int c = 0; c < 4; ++c)
             if (c <= k && c < t)
-              res[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s4], S[soff(16 * (p0 + k) + 4 * s4 + kq) + 16 * (p0 + c) + nn], res[c], 0, 0, 0);
+              rs2[c][s4 & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s4], S[soff(16 * (p0 + k) + 4 * s4 + kq) + 16 * (p0 + c) + nn], rs2[c][s4 & 1], 0, 0, 0);
       }
     }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) res[c] = rs2[c][0] + rs2[c][1];
+    LEAF_STAMP(13);
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < 4; ++c)
@@ -509,7 +551,7 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
     __syncthreads();
     // stage B: M21[a][c] = - sum_{k <= a} M[p0+t+a][p0+t+k] T[k][c], this wave owns tile column c = idx
 #pragma unroll
-    for (int a = 0; a < 4; ++a) res[a] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    for (int a = 0; a < 4; ++a) rs2[a][0] = rs2[a][1] = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       if (k < t) {
@@ -521,9 +563,12 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
 #pragma unroll
           for (int a = 0; a < 4; ++a)
             if (a >= k && a < t)
-              res[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(S[soff(16 * (p0 + t + a) + nn) + 16 * (p0 + t + k) + 4 * s4 + kq], bv[s4], res[a], 0, 0, 0);
+              rs2[a][s4 & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(S[soff(16 * (p0 + t + a) + nn) + 16 * (p0 + t + k) + 4 * s4 + kq], bv[s4], rs2[a][s4 & 1], 0, 0, 0);
       }
     }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) res[a] = rs2[a][0] + rs2[a][1];
+    LEAF_STAMP(14);
     __syncthreads();
 #pragma unroll
     for (int a = 0; a < 4; ++a) {

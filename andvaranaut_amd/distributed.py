@@ -80,6 +80,9 @@ class DistGP:
             self.dinv = torch.zeros(self.pwt * MINV, dtype=torch.float64, device=self.dev)
             self.info = torch.zeros(4, dtype=torch.int32, device=self.dev)
             self.out = torch.zeros(16, dtype=torch.float64, device=self.dev)
+            # look-ahead inside the rank: the owner of the next panel updates, factors and stages it on this stream while
+            # its bulk updates with the current panel run on the main stream (round 2; one rank, N = 65536: see DESIGN.md)
+            self.side = torch.cuda.Stream(device=self.dev)
         self.kids = (ctypes.c_int * _lib.MAX_KERN)(*[_lib.KERNEL_IDS[k] for k in self.kerns] + [0] * (_lib.MAX_KERN - self.nkern))
         self.opids = (ctypes.c_int * _lib.MAX_KERN)(*[_lib.OP_IDS[o] for o in self.ops] + [0] * (_lib.MAX_KERN - len(self.ops)))
 
@@ -155,23 +158,39 @@ class DistGP:
                 self._factor(0)
                 self._stage(0, self.P[0])
             work = self._bcast(0)
+            main = torch.cuda.current_stream(self.dev)
+            staged = None  # event behind the side stream's staging of the panel the next step consumes
             for j in range(self.npan):
                 buf = self.P[j % 2]
                 if work is not None:
                     work.wait()
+                if staged is not None:
+                    main.wait_event(staged)
+                    staged = None
                 if _keep:
                     self._keep_panel(j, buf)
                 jn = j + 1
                 work = None
                 if jn < self.npan:
                     if owner(jn) == self.rank:
-                        self._update(jn, j, buf)
-                        self._factor(jn)
-                        self._stage(jn, self.P[jn % 2])
-                    work = self._bcast(jn)  # posted before the bulk updates so that it overlaps them
+                        # everything queued on the main stream so far (the previous step's updates of panel jn, the reads
+                        # of the buffer that is about to be restaged) precedes the side stream's work
+                        ready = torch.cuda.Event()
+                        ready.record(main)
+                        with torch.cuda.stream(self.side):
+                            self.side.wait_event(ready)
+                            self._update(jn, j, buf)
+                            self._factor(jn)
+                            self._stage(jn, self.P[jn % 2])
+                            staged = torch.cuda.Event()
+                            staged.record(self.side)
+                            work = self._bcast(jn)  # posted behind the staging: RCCL orders itself after the side stream
+                    else:
+                        work = self._bcast(jn)  # posted before the bulk updates so that it overlaps them
                 for jt in self.own:
                     if jt > jn:
                         self._update(jt, j, buf)
+            main.wait_stream(self.side)
             # local pieces of sum log L_ii and |beta|^2, then one small all-reduce
             acc = torch.zeros(3, dtype=torch.float64, device=self.dev)
             for j in self.own:

@@ -424,3 +424,49 @@ def test_overflowed_transform_is_minus_infinity_not_an_error():
     with np.errstate(all="ignore"):
         v, g = model.logp_dlogp(q, boom)
     assert v == -np.inf and np.all(g == 0)
+
+
+def test_gauss_hermite_reversion_matches_the_per_point_loop():
+    """SURVEY 8a row A6 (gpmcmc.py:545-569): the vectorised __gh_stats against a literal restatement of the reference's
+    per-point loop -- mean / variance, normvar on and off, EI towards max and min, a non-zero mean function and a
+    non-trivial reversion (logarithmic warp)."""
+    from andvaranaut_amd import GPMCMC
+    from andvaranaut_amd.transform import logarithm
+
+    priors = [st.uniform(loc=0, scale=2), st.uniform(loc=1, scale=0.5)]
+    fun = lambda x: np.array([np.exp(x[0] - x[1])])  # noqa: E731
+    rng = np.random.default_rng(3)
+    M = 23
+    x = rng.uniform([0, 1], [2, 1.5], (M, 2))
+    mu = rng.normal(0.2, 0.8, (M, 1))
+    var = rng.uniform(1e-4, 0.5, (M, 1))
+
+    def loop(g, x, y, yv, normvar, deg, EI, EIopt):  # gpmcmc.py:545-569, line by line
+        y, yv = y.copy(), yv.copy()
+        xi, wi = np.polynomial.hermite.hermgauss(deg)
+        for i in range(len(y)):
+            yi = np.sqrt(2 * yv[i, 0]) * xi + y[i, 0]
+            yir = g.yconrevs[0].rev(yi) + g.mean(x[i, :])
+            if EI:
+                ydiff = yir - g.yopt if EIopt == "max" else g.yopt - yir
+                ydiff = np.where(ydiff > 0.0, ydiff, 0.0)
+                y[i, 0] = 1 / np.sqrt(np.pi) * np.sum(wi * ydiff)
+            else:
+                y[i, 0] = 1 / np.sqrt(np.pi) * np.sum(wi * yir)
+            ym2 = 1 / np.sqrt(np.pi) * np.sum(wi * np.power(yir, 2))
+            yv[i, 0] = ym2 - y[i, 0] ** 2
+        if normvar:
+            yv /= np.power(y, 2)
+        return y, yv
+
+    for mean in (0, lambda xx: np.array([0.3 * xx[0] - 0.1])):
+        g = GPMCMC(kernel="RBF", noise=True, yconrevs=[logarithm()], mean=mean, nx=2, ny=1, priors=priors, target=fun,
+                   verbose=False)
+        g.yopt = 0.9
+        for normvar in (True, False):
+            for deg in (8, 5):
+                for EI, EIopt in ((False, None), (True, "max"), (True, "min")):
+                    got = g._GPMCMC__gh_stats(x, mu.copy(), var.copy(), normvar, deg, EI=EI, EIopt=EIopt)
+                    ref = loop(g, x, mu, var, normvar, deg, EI, EIopt)
+                    assert np.allclose(got[0], ref[0], rtol=1e-13, atol=1e-15), (normvar, deg, EI, EIopt)
+                    assert np.allclose(got[1], ref[1], rtol=1e-11, atol=1e-14), (normvar, deg, EI, EIopt)

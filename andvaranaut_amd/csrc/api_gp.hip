@@ -24,6 +24,7 @@ struct mi_gp_handle {
   hipEvent_t wait_ev;               // recorded on the main stream behind the (a2) update of tile columns wait_col + 1 ..:
   int wait_col;                     // the panel stream waits for it after the leaf + strip of tile column wait_col
   // tuning options (mi_gp_set_option), all per handle
+  int chain_prio;   // s_setprio(3) in the GEMM launches of the panel stream (option 16; the leaf and strip kernels always raise it)
   int lookahead;    // 0 never, 1 by size (default: from LOOKAHEAD_MIN_TILES tile columns on), 2 always
   int lowocc_thr;   // trailing sizes (tile columns) at or below which bulk updates run one workgroup per CU
   int w_thr[3];     // trailing sizes (tile columns) above which the super-panel is 16 / 8 / 4 tiles wide
@@ -134,6 +135,7 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   }
   h->ev_next = 0;
   h->lookahead = 1;
+  h->chain_prio = 1;  // N = 8192: 6.06 -> 5.94 ms, N = 16384: 28.11 -> 27.74 ms (interleaved A/B)
   h->small_below = GemmParams().small_below;
   h->band_rows = GemmParams().band;
   // round-2 A/B (tools/dev_ab_opts.py, interleaved in one process): bulk updates at one workgroup per CU whenever the
@@ -196,6 +198,7 @@ extern "C" int mi_gp_set_option(mi_gp_handle* h, int what, int value) {
   else if (what == 7) h->small_below = value;
   else if (what == 8) h->lowocc_thr = value;
   else if (what == 14) h->band_rows = value;
+  else if (what == 16) h->chain_prio = value;
   else {
     snprintf(h->err, sizeof(h->err), "mi_gp_set_option: unknown option %d", what);
     return -1;
@@ -240,6 +243,7 @@ static hipError_t syrk_trapezoid(mi_gp_handle* h, double* A, long lda, int ntr, 
                                  hipStream_t st, int one_per_cu = 0) {
   GemmParams p;
   p.one_per_cu = one_per_cu;
+  p.hiprio = (st == h->pstream && h->chain_prio) ? 1 : 0;
   p.small_below = h->small_below;
   p.band = h->band_rows;
   p.A = A + (long)r0 * 128 * lda + (long)k0 * 128;

@@ -353,6 +353,7 @@ __device__ __forceinline__ void chunk_store(char* __restrict__ lds, unsigned lof
 template <bool A_KMAJOR, bool B_KMAJOR>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel_s(GemmParams p) {
   using vs::BKS; using vs::OPER_S; using vs::NQS; using vs::LDS_S; using vs::TS;
+  if (p.hiprio) __builtin_amdgcn_s_setprio(3);  // panel-chain launches: win the SIMD's issue arbitration against bulk waves
   __shared__ __attribute__((aligned(16))) double smem[4 * vs::OPER_S];
   double* As = smem;
   double* Bs = smem + 2 * OPER_S;

@@ -588,6 +588,7 @@ __global__ __launch_bounds__(256, 1) void potrf_leaf128_kernel(double* __restric
                                                                 double* __restrict__ minv, int col0,
                                                                 int* __restrict__ info) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
+  __builtin_amdgcn_s_setprio(3);  // the leaf is the panel chain: win the issue arbitration against bulk GEMM waves on its CU
   potrf_leaf128_body(Ablk, lda, minv, col0, info, smem);
 }
 
@@ -681,6 +682,7 @@ __device__ __forceinline__ void trsm_strip128_body(const double* __restrict__ mi
 template <int RG>
 __global__ __launch_bounds__(256) void trsm_strip128_kernel(const double* __restrict__ minv, double* __restrict__ B, long ldb,
                                                              long strideB) {
+  __builtin_amdgcn_s_setprio(3);
   trsm_strip128_body<RG>(minv + (long)blockIdx.y * (LEAF * LEAF), B + (long)blockIdx.y * strideB, ldb, blockIdx.x);
 }
 

@@ -20,6 +20,7 @@ struct GemmParams {
   // launcher options (per call; a handle keeps its own values, mi_gp_set_option 7 / 14)
   int small_below = 1024;           // launches with fewer 128x128 tiles than this run on the 64x64-tile kernel
   int band = 8;                     // band height (tile rows) of the band-column-major order of uniform-k trapezoid launches, 0 = row-major
+  int hiprio = 0;                   // 64x64-tile kernel only: raise the waves' issue priority (launches on the panel chain)
   int one_per_cu = 0;               // request > half a CU's LDS so that one workgroup per CU runs (leaves room for
                                     // the panel chain's leaf / strip kernels next to a bulk update)
 };

@@ -194,7 +194,7 @@ def test_tuning_options_do_not_change_results():
     theta = orc.synth_theta(6)
     gp = MiGP(X, y, "Matern52", need_grad=False)
     ref = gp.lml(theta)
-    for what, value in [(0, 0), (0, 2), (8, 1 << 20), (8, 0), (14, 0), (14, 4), (7, 0), (7, 100000), (2, 2), (2, 8)]:
+    for what, value in [(0, 0), (0, 2), (8, 1 << 20), (8, 0), (14, 0), (14, 4), (16, 0), (16, 1), (7, 0), (7, 100000), (2, 2), (2, 8)]:
         gp.set_option(what, value)
         v = gp.lml(theta)
         if what in (2, 7):  # the super-panel width regroups the k-sums of the updates, the tile size their MFMA order

@@ -43,7 +43,6 @@ struct mi_gp_handle {
   double* grad_host;    // pinned [ntheta]
   int* info_dev;
   double* out_host;     // pinned [16]
-  int* info_host;       // pinned
   double* theta_host;   // pinned
   // profiling
   int prof_level;
@@ -84,7 +83,6 @@ static void release_handle(mi_gp_handle* h) {
   (void)hipFree(h->alpha_dev); (void)hipFree(h->part_dev); (void)hipFree(h->gxs_dev); (void)hipFree(h->grad_dev);
   if (h->grad_host) (void)hipHostFree(h->grad_host);
   if (h->out_host) (void)hipHostFree(h->out_host);
-  if (h->info_host) (void)hipHostFree(h->info_host);
   if (h->theta_host) (void)hipHostFree(h->theta_host);
   for (int i = 0; i < 8; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
   for (auto& ev : h->gemm_ev) (void)hipEventDestroy(ev);
@@ -152,7 +150,6 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   if (e == hipSuccess) e = hipHostMalloc(&h->grad_host, sizeof(double) * h->ntheta);
   if (e == hipSuccess) e = hipMalloc(&h->info_dev, sizeof(int) * 4);
   if (e == hipSuccess) e = hipHostMalloc(&h->out_host, sizeof(double) * 16);
-  if (e == hipSuccess) e = hipHostMalloc(&h->info_host, sizeof(int) * 4);
   if (e == hipSuccess) e = hipHostMalloc(&h->theta_host, sizeof(double) * h->ntheta);
   for (int i = 0; i < 8 && e == hipSuccess; ++i) e = hipEventCreate(&h->ev[i]);
   if (e == hipSuccess) e = gemm_f64_enable_lds();
@@ -376,11 +373,11 @@ static int enqueue_factor(mi_gp_handle* h, int noise_form, bool prof) {
   if (prof) (void)hipEventRecord(h->ev[0], h->stream);
   HCK(launch_assemble(h->spec, h->theta_dev, h->buf.X_dev, h->n, h->buf.X_dev, h->n, h->buf.K_dev, h->buf.lda, h->np,
                       h->np, 1, noise_form, h->stream, 0, h->diag_dev), "assemble");
-  HCK(launch_set_yrows(h->buf.K_dev, h->buf.lda, h->np, h->np, h->buf.y_dev, h->n, h->stream), "set_yrows");
+  HCK(launch_set_yrows(h->buf.K_dev, h->buf.lda, h->np, h->np, h->buf.y_dev, h->n, h->stream, h->info_dev), "set_yrows");
   if (prof) (void)hipEventRecord(h->ev[1], h->stream);
   HCK(cholesky(h, h->buf.K_dev, h->buf.lda, h->ntc + 1, h->ntc), "cholesky");
   if (prof) (void)hipEventRecord(h->ev[2], h->stream);
-  HCK(launch_lml_reduce(h->buf.K_dev, h->buf.lda, h->buf.K_dev + (long)h->np * h->buf.lda, h->n, h->out_dev, h->stream), "lml_reduce");
+  HCK(launch_lml_reduce(h->buf.K_dev, h->buf.lda, h->buf.K_dev + (long)h->np * h->buf.lda, h->n, h->out_dev, h->stream, h->info_dev), "lml_reduce");
   if (prof) (void)hipEventRecord(h->ev[3], h->stream);
   return 0;
 }
@@ -390,7 +387,6 @@ static hipError_t inverse_transpose(mi_gp_handle* h);
 
 static int download_results(mi_gp_handle* h, int what) {
   HCK(hipMemcpyAsync(h->out_host, h->out_dev, sizeof(double) * 16, hipMemcpyDeviceToHost, h->stream), "out download");
-  HCK(hipMemcpyAsync(h->info_host, h->info_dev, sizeof(int) * 4, hipMemcpyDeviceToHost, h->stream), "info download");
   if (what == 2)
     HCK(hipMemcpyAsync(h->grad_host, h->grad_dev, sizeof(double) * h->ntheta, hipMemcpyDeviceToHost, h->stream), "grad download");
   return 0;
@@ -399,11 +395,6 @@ static int download_results(mi_gp_handle* h, int what) {
 static int enqueue_all(mi_gp_handle* h, int what, bool prof) {
   if (int r = enqueue_factor(h, what == 1 ? 1 : 0, prof)) return r;
   if (what == 2) return enqueue_gradient(h, prof);
-  return 0;
-}
-
-static int reset_flags(mi_gp_handle* h) {
-  HCK(hipMemsetAsync(h->info_dev, 0x7f, sizeof(int) * 4, h->stream), "info reset");
   return 0;
 }
 
@@ -418,7 +409,6 @@ static int run_evaluation(mi_gp_handle* h, int what) {
   h->gemm_ev_used = 0;
   h->gemm_flops_acc = 0.0;
   HCK(hipMemcpyAsync(h->theta_dev, h->theta_host, sizeof(double) * h->ntheta, hipMemcpyHostToDevice, h->stream), "theta upload");
-  if (int r = reset_flags(h)) return r;
   if (int r = enqueue_all(h, what, prof)) return r;
   return download_results(h, what);
 }
@@ -460,7 +450,7 @@ static int factor_internal(mi_gp_handle* h, const double* theta, int what) {
       (void)hipEventElapsedTime(&ms, h->ev[6], h->ev[7]); h->t_contract_ms = ms;
     }
   }
-  const int info = h->info_host[0];
+  const int info = (int)h->out_host[3];  // forwarded by lml_reduce_kernel (reset by set_yrows_kernel)
   if (info != 0x7f7f7f7f) return info;  // 1-based index of the first bad pivot
   return 0;
 }

@@ -272,7 +272,9 @@ __global__ __launch_bounds__(256, (KID_STATIC >= 0 && KID_STATIC != KID_RATQUAD)
 
 // rows [row0, row0+128) x cols [0, cols_pad): zero, except row row0 = y^T (first n entries)
 __global__ void set_yrows_kernel(double* __restrict__ K, long ldk, int row0, int cols_pad,
-                                 const double* __restrict__ y, int n) {
+                                 const double* __restrict__ y, int n, int* __restrict__ info) {
+  // info (optional): the evaluation's bad-pivot word starts as "none" here (a memset less per evaluation)
+  if (info && blockIdx.x == 0 && threadIdx.x == 0) info[0] = 0x7f7f7f7f;
   const long total = 128L * cols_pad;
   for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     const int r = (int)(e / cols_pad), c = (int)(e % cols_pad);
@@ -287,7 +289,7 @@ __global__ void set_yrows_kernel(double* __restrict__ K, long ldk, int row0, int
 // latency), partial sums combined in a fixed order (bit-reproducible).
 __global__ __launch_bounds__(256) void lml_reduce_kernel(const double* __restrict__ L, long ld,
                                                          const double* __restrict__ beta, int n,
-                                                         double* __restrict__ out) {
+                                                         double* __restrict__ out, const int* __restrict__ info) {
   __shared__ double s1[256], s2[256];
   double a = 0.0, b = 0.0;
   for (int i0 = threadIdx.x; i0 < n; i0 += 256 * 16) {
@@ -318,6 +320,7 @@ __global__ __launch_bounds__(256) void lml_reduce_kernel(const double* __restric
     out[1] = s1[0];
     out[2] = s2[0];
     out[0] = -0.5 * (double)n * 1.8378770664093453 - 0.5 * s2[0] - s1[0];
+    if (info) out[3] = (double)info[0];  // the bad-pivot word rides in the same download as the scalars
   }
 }
 
@@ -351,16 +354,18 @@ hipError_t launch_assemble(const KernSpec& spec, const double* theta, const doub
   return hipGetLastError();
 }
 
-hipError_t launch_set_yrows(double* K, long ldk, int row0, int cols_pad, const double* y, int n, hipStream_t stream) {
+hipError_t launch_set_yrows(double* K, long ldk, int row0, int cols_pad, const double* y, int n, hipStream_t stream,
+                            int* info) {
   const long total = 128L * cols_pad;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  set_yrows_kernel<<<blocks, 256, 0, stream>>>(K, ldk, row0, cols_pad, y, n);
+  set_yrows_kernel<<<blocks, 256, 0, stream>>>(K, ldk, row0, cols_pad, y, n, info);
   return hipGetLastError();
 }
 
-hipError_t launch_lml_reduce(const double* L, long ld, const double* beta, int n, double* out, hipStream_t stream) {
-  lml_reduce_kernel<<<1, 256, 0, stream>>>(L, ld, beta, n, out);
+hipError_t launch_lml_reduce(const double* L, long ld, const double* beta, int n, double* out, hipStream_t stream,
+                             const int* info) {
+  lml_reduce_kernel<<<1, 256, 0, stream>>>(L, ld, beta, n, out, info);
   return hipGetLastError();
 }
 

@@ -59,8 +59,12 @@ hipError_t launch_assemble(const KernSpec& spec, const double* theta, const doub
                            hipStream_t stream, int diag_shift = -2147483647 - 1, const double* extra_diag = nullptr);
 // diag_shift (sym=0 only): local element (i, j) is on the global diagonal when i + diag_shift == j
 // (rectangular blocks of a distributed covariance); the default means "no diagonal" (cross-covariance).
-hipError_t launch_set_yrows(double* K, long ldk, int row0, int cols_pad, const double* y, int n, hipStream_t stream);
-hipError_t launch_lml_reduce(const double* L, long ld, const double* beta, int n, double* out, hipStream_t stream);
+// info (optional): reset to 0x7f7f7f7f ("no bad pivot") by the same launch
+hipError_t launch_set_yrows(double* K, long ldk, int row0, int cols_pad, const double* y, int n, hipStream_t stream,
+                            int* info = nullptr);
+// info (optional): its first word is forwarded as out[3]
+hipError_t launch_lml_reduce(const double* L, long ld, const double* beta, int n, double* out, hipStream_t stream,
+                             const int* info = nullptr);
 
 // ---------------------------------------------------------------- grad_predict.hip
 hipError_t launch_set_identity_blocks(double* U, long ld, int nblocks, hipStream_t stream);

@@ -406,7 +406,7 @@ def main():
             if rank == 0 and line is not None:
                 line["sharded"] = {"error": f"not finished after {args.sharded_timeout:.0f} s (rank 0 gave up waiting)"}
                 print(json.dumps(line), flush=True)
-            os._exit(0 if rank == 0 else 3)
+            os._exit(0)  # every rank leaves cleanly: the replicas' line stands on its own
 
         with Deadline(args.sharded_timeout, expire):
             try:

@@ -173,8 +173,10 @@ struct ElimStep<15> {
 };
 template <int C>
 struct ScaleCols {
+  // l[C] = a[C] * rs of lane C: ONE dpp fmac into a zeroed accumulator (round 1: broadcast move + multiply, 25 cycles)
   static __device__ __forceinline__ void run(const double (&a)[16], double rs, double (&l)[16]) {
-    l[C] = a[C] * mov_rowbcast<C>(rs);
+    l[C] = 0.0;
+    fmac_rowbcast<C>(l[C], rs, a[C]);
     ScaleCols<C + 1>::run(a, rs, l);
   }
 };
@@ -299,6 +301,7 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
     // normalise: L[r][c] = a[c] * rsqrt(p_c); lane c holds p_c = a[c]
     const double rs = fast_rsqrt(a[r]);
     double l[SB];
+    asm volatile("s_nop 1" ::: "memory");  // rs was written by VALU just now: two wait states before the DPP reads below
     ScaleCols<0>::run(a, rs, l);
     double* row = S + soff(j0 + r) + j0;
     double* LdT = LdT2 + (jb & 1) * SB * SB;
@@ -349,13 +352,6 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
   // tile (rb, cb) of the LDS image as MFMA operands / result:
   //   A operand: lane holds [16 rb + n][16 cb + 4 s + kq];  B operand: [16 rb + 4 s + kq][16 cb + n];  D: [16 rb + kq + 4 r][16 cb + n]
   const int nn = lane & 15, kq = lane >> 4;
-  auto prod = [&](double4_t acc, int arb, int acb, int brb, int bcb) {
-    const double* ap = S + soff(16 * arb + nn) + 16 * acb + kq;
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4)
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[4 * s4], S[soff(16 * brb + 4 * s4 + kq) + 16 * bcb + nn], acc, 0, 0, 0);
-    return acc;
-  };
   auto put = [&](const double4_t& v, int rb, int cb) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) S[soff(16 * rb + kq + 4 * r) + 16 * cb + nn] = v[r];

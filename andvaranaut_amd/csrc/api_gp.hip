@@ -355,11 +355,13 @@ static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int nt
     } else {
       CKE(syrk_trapezoid(h, A, lda, ntr, n1, wn, J, w, T));
     }
-    CKE(chol_panel(h, A, lda, ntr, n1, wn, P));
     // (b) the rest of the trailing matrix, concurrently with that panel factorisation; once the panel chain is the
-    // critical path the bulk update runs one workgroup per CU so that a leaf / strip workgroup fits beside it everywhere
+    // critical path the bulk update runs one workgroup per CU so that a leaf / strip workgroup fits beside it everywhere.
+    // Enqueued BEFORE the chain's ~25 launches: when the host runs only just ahead of the device (under rocprofv3 it does:
+    // 150-200 us of idle main stream per super-panel at N = 8192) the bulk update is already queued when (a2) ends.
     if (n1 + wn < ntc)
       CKE(syrk_trapezoid(h, A, lda, ntr, n1 + wn, ntc - n1 - wn, J, w, T, (P != T && ntc - n1 <= h->lowocc_thr) ? 1 : 0));
+    CKE(chol_panel(h, A, lda, ntr, n1, wn, P));
     J = n1;
     w = wn;
   }

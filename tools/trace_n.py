@@ -11,6 +11,8 @@ what = sys.argv[3] if len(sys.argv) > 3 else "lml"
 X, y = orc.synth_problem(N, d, seed=0)
 theta = orc.synth_theta(d)
 gp = MiGP(X, y, "RBF", need_grad=(what != "lml"))
+for kv in filter(None, os.environ.get("MIGP_OPTS", "").split(",")):  # e.g. MIGP_OPTS=0=2,16=0
+    gp.set_option(int(kv.split("=")[0]), int(kv.split("=")[1]))
 import time
 for i in range(8):
     t0 = time.perf_counter()

@@ -316,6 +316,7 @@ constexpr int BKS = 16;
 constexpr int LDS_S = 80;  // 64 + 16: odd k rows land 16 bank-pairs away from even ones
 constexpr int OPER_S = BKS * LDS_S;
 constexpr int NQS = TS * BKS / 2 / 256;  // 2
+constexpr int NBUF = 3;                  // LDS buffers per operand (see the pipeline note in the kernel)
 
 template <bool KMAJOR>
 __device__ __forceinline__ void chunk_offsets(long ld, int tid, unsigned& goff, unsigned& loff, long& gstride) {
@@ -354,9 +355,9 @@ template <bool A_KMAJOR, bool B_KMAJOR>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel_s(GemmParams p) {
   using vs::BKS; using vs::OPER_S; using vs::NQS; using vs::LDS_S; using vs::TS;
   if (p.hiprio) __builtin_amdgcn_s_setprio(3);  // panel-chain launches: win the SIMD's issue arbitration against bulk waves
-  __shared__ __attribute__((aligned(16))) double smem[4 * vs::OPER_S];
+  __shared__ __attribute__((aligned(16))) double smem[2 * vs::NBUF * vs::OPER_S];
   double* As = smem;
-  double* Bs = smem + 2 * OPER_S;
+  double* Bs = smem + vs::NBUF * OPER_S;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -395,23 +396,33 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel_s(GemmParams p) {
   const long stepB = (B_KMAJOR ? (long)BKS * p.ldb : (long)BKS) * 8;
   char* Asb = reinterpret_cast<char*>(As);
   char* Bsb = reinterpret_cast<char*>(Bs);
-  // Global -> register prefetch runs FOUR chunks ahead through a ring of register sets (set c & 3 holds chunk c until it
-  // is written to LDS buffer c & 1 during chunk c - 1).  A chunk is only 16 MFMAs per wave (0.43 us): with the one-chunk
-  // prefetch of round 1 every chunk waited for its global load (1.4 us per chunk, k = 512 on an idle chip: 50 us per tile);
-  // these launches sit on the factorisation's critical path with one workgroup per CU at most.
-  constexpr int PF = 4;
-  double2_t ra[PF][NQS], rb[PF][NQS];
+  // Pipeline (chunk = 16 k = 16 MFMAs per wave, 0.43 us): chunk c is requested from global memory during chunk c - 4
+  // (one-chunk prefetch, round 1: every chunk waited for its load, 1.4 us per chunk), parked in register set c % 3,
+  // written to LDS buffer c % 3 at the end of chunk c - 2, and its first operand fragments are read during the last
+  // k-step of chunk c - 1 -- BEFORE that chunk's barrier, which is possible because the buffer became visible one barrier
+  // earlier.  With two LDS buffers the fragment read followed the barrier and every chunk began with an LDS round trip
+  // (~150 cycles of 1024 + 150); the third buffer costs 20 KB (60 KB per workgroup, two workgroups per CU still fit).
+  constexpr int NB = vs::NBUF;  // 3
+  double2_t ra[NB][NQS], rb[NB][NQS];
+  auto advance = [&](int next_chunk) {  // chunks beyond the last are redundant reloads of the last one, never consumed
+    const bool adv = next_chunk < nchunk;
+    Ag += adv ? stepA : 0;
+    Bg += adv ? stepB : 0;
+  };
   if (nchunk > 0) {
 #pragma unroll
-    for (int u = 0; u < PF; ++u) {
+    for (int u = 0; u < NB; ++u) {
       vs::chunk_load(Ag, gA, sA, ra[u]);
       vs::chunk_load(Bg, gB, sB, rb[u]);
-      const bool adv = (u + 1 < nchunk);  // chunks beyond the last are redundant reloads of the last one, never consumed
-      Ag += adv ? stepA : 0;
-      Bg += adv ? stepB : 0;
+      advance(u + 1);
     }
     vs::chunk_store<A_KMAJOR>(Asb, lA, ra[0]);
     vs::chunk_store<B_KMAJOR>(Bsb, lB, rb[0]);
+    vs::chunk_store<A_KMAJOR>(Asb + OPER_S * 8, lA, ra[1]);
+    vs::chunk_store<B_KMAJOR>(Bsb + OPER_S * 8, lB, rb[1]);
+    vs::chunk_load(Ag, gA, sA, ra[0]);  // chunk 3
+    vs::chunk_load(Bg, gB, sB, rb[0]);
+    advance(4);
   }
   // C tile early: these launches are latency-bound, the read hides under the whole k loop
   const int kq = lane >> 4, l15 = lane & 15;
@@ -439,27 +450,29 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel_s(GemmParams p) {
     fa[set][0] = ap[0]; fa[set][1] = ap[16]; fb[set][0] = bp[0]; fb[set][1] = bp[16];
   };
   if (nchunk > 0) load_frags(0, 0, 0);
-  // one chunk; S = c & 3 selects the register set that is refilled (with chunk c + 4), S & 1 the LDS buffer consumed
+  // one chunk c; S = c % 3: LDS buffer consumed; register set (S + 1) % 3 is refilled with chunk c + 4; register set and
+  // LDS buffer (S + 2) % 3 take part in the hand-over of chunk c + 2
   auto chunk_body = [&](int c, auto Sc) {
     constexpr int sidx = decltype(Sc)::value;
-    constexpr int boff = (sidx & 1) * OPER_S;
+    constexpr int boff = sidx * OPER_S;
+    constexpr int s1 = (sidx + 1) % NB, s2 = (sidx + 2) % NB;
 #pragma unroll
     for (int kk = 0; kk < BKS / 4; ++kk) {
       const int cur = kk & 1;
       __builtin_amdgcn_sched_barrier(0);
       if (kk == 0) {
-        vs::chunk_load(Ag, gA, sA, ra[sidx]);
-        vs::chunk_load(Bg, gB, sB, rb[sidx]);
+        vs::chunk_load(Ag, gA, sA, ra[s1]);
+        vs::chunk_load(Bg, gB, sB, rb[s1]);
       }
       if (kk + 1 < BKS / 4) load_frags(cur ^ 1, boff, kk + 1);
+      else load_frags(cur ^ 1, s1 * OPER_S, 0);  // first fragments of the next chunk, ahead of the barrier
       acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[cur][0], fb[cur][0], acc[0][0], 0, 0, 0);
       acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[cur][0], fb[cur][1], acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[cur][1], fb[cur][0], acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[cur][1], fb[cur][1], acc[1][1], 0, 0, 0);
       if (kk == BKS / 4 - 1) {
-        constexpr int noff = (boff ^ OPER_S) * 8;
-        vs::chunk_store<A_KMAJOR>(Asb + noff, lA, ra[(sidx + 1) & (PF - 1)]);
-        vs::chunk_store<B_KMAJOR>(Bsb + noff, lB, rb[(sidx + 1) & (PF - 1)]);
+        vs::chunk_store<A_KMAJOR>(Asb + s2 * OPER_S * 8, lA, ra[s2]);
+        vs::chunk_store<B_KMAJOR>(Bsb + s2 * OPER_S * 8, lB, rb[s2]);
       }
       if (kk == 0) {
 #pragma unroll
@@ -481,27 +494,23 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel_s(GemmParams p) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
         }
       }
     }
-    const bool adv = (c + PF + 1 < nchunk);
-    Ag += adv ? stepA : 0;
-    Bg += adv ? stepB : 0;
+    advance(c + 5);
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
-    load_frags(0, boff ^ OPER_S, 0);
   };
   int c = 0;
-  for (; c + 4 <= nchunk; c += 4) {
+  for (; c + 3 <= nchunk; c += 3) {
     chunk_body(c, std::integral_constant<int, 0>());
     chunk_body(c + 1, std::integral_constant<int, 1>());
     chunk_body(c + 2, std::integral_constant<int, 2>());
-    chunk_body(c + 3, std::integral_constant<int, 3>());
   }
-  if (c < nchunk) chunk_body(c, std::integral_constant<int, 0>());  // k not a multiple of 64: c is a multiple of 4 here
+  if (c < nchunk) chunk_body(c, std::integral_constant<int, 0>());  // c is a multiple of 3 here
   if (c + 1 < nchunk) chunk_body(c + 1, std::integral_constant<int, 1>());
-  if (c + 2 < nchunk) chunk_body(c + 2, std::integral_constant<int, 2>());
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -534,8 +543,8 @@ hipError_t launch_gemm_f64(const GemmParams& p, int opA_kmajor, int opB_kmajor, 
     q.mt = 2 * p.mt;
     q.nt = 2 * p.nt;
     dim3 grid(tile_count(q), 1, batch), block(256);
-    // one_per_cu: unused dynamic LDS on top of the 40 KB static image pushes the request over half a CU
-    const size_t pad = p.one_per_cu ? LDS_ONE_PER_CU - sizeof(double) * 4 * vs::OPER_S : 0;
+    // one_per_cu: unused dynamic LDS on top of the 60 KB static image pushes the request over half a CU
+    const size_t pad = p.one_per_cu ? LDS_ONE_PER_CU - sizeof(double) * 2 * vs::NBUF * vs::OPER_S : 0;
     if (!opA_kmajor && !opB_kmajor) gemm_f64_kernel_s<false, false><<<grid, block, pad, stream>>>(q);
     else if (!opA_kmajor && opB_kmajor) gemm_f64_kernel_s<false, true><<<grid, block, pad, stream>>>(q);
     else if (opA_kmajor && opB_kmajor) gemm_f64_kernel_s<true, true><<<grid, block, pad, stream>>>(q);

@@ -421,8 +421,11 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(N, d, args.kernel, full=not args.cpu_baseline_sample)
         print(json.dumps(line), flush=True)
-    dist.barrier()  # rank 0's roofline pass / CPU baseline run after the timed region: leave together
-    dist.destroy_process_group()
+    # rank 0's roofline pass / CPU baseline run after the timed region: leave together -- but never hang on a rank that
+    # died in the sharded sub-record after the line was printed
+    with Deadline(1800.0 if world == 1 else 120.0, lambda: os._exit(0)):
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,9 @@
+"""bench.py against another build of the library: python tools/dev_bench_lib.py LIB [bench.py flags]"""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from andvaranaut_amd import _lib
+if sys.argv[1] != "default":
+    _lib.LIB_PATH = os.path.abspath(sys.argv[1])
+sys.argv = ["bench.py"] + sys.argv[2:]
+import bench
+bench.main()

@@ -368,6 +368,48 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
   //                the rank-16 MFMA update to every other trailing tile and stream column block jb out.
   for (int jb = 0; jb < LEAF / SB; ++jb) {
     const int j0 = jb * SB;
+    // trailing tiles (tr, tc), 1 <= tr < q, tc <= tr, of this iteration's rank-16 update (tile (0,0), the next diagonal
+    // block, belongs to wave 0's chain).  They are processed up to FOUR at a time with their MFMAs interleaved: a chain of
+    // four dependent fp64 MFMAs takes ~1k cycles, and so do four independent chains (16 x 64 issue cycles).  The first
+    // nh tiles are dealt round-robin to waves 1..3; in the two longest iterations wave 0 takes the last n0 tiles after
+    // its chain instead of idling (jb = 0: 27 tiles = 3 x 8 + 3, jb = 1: 20 = 3 x 6 + 2: two rounds per wave, not three).
+    const int q = LEAF / SB - 1 - jb;  // trailing tiles per dimension
+    const int ntile = q * (q + 1) / 2 - 1;
+    const int n0 = jb == 0 ? 3 : (jb <= 2 ? 2 : 0);
+    const int nh = ntile - n0;
+    const int ln = lane & 15, lq = lane >> 4;
+    auto tile_of = [&](int e, int& r0, int& c0) {  // e-th trailing tile (tile (0,0) excluded) -> first row / column
+      int tr = 1;
+      while ((tr + 1) * (tr + 2) / 2 <= e + 1) ++tr;
+      const int tc = e + 1 - tr * (tr + 1) / 2;
+      r0 = j0 + SB + 16 * tr;
+      c0 = j0 + SB + 16 * tc;
+    };
+    auto batch = [&](auto NBc, int e0, int estride) {  // tiles e0, e0 + estride, ...: no predicates, one scheduling region
+      constexpr int NBT = decltype(NBc)::value;
+      double av[NBT][4], bv[NBT][4];
+      double4_t acc[NBT];
+      int r0[NBT], c0[NBT];
+#pragma unroll
+      for (int u = 0; u < NBT; ++u) {
+        tile_of(e0 + estride * u, r0[u], c0[u]);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          av[u][s4] = S[soff(r0[u] + ln) + j0 + 4 * s4 + lq];
+          bv[u][s4] = S[soff(c0[u] + ln) + j0 + 4 * s4 + lq];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[u][r] = S[soff(r0[u] + lq + 4 * r) + c0[u] + ln];
+      }
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int u = 0; u < NBT; ++u) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[u][s4], bv[u][s4], acc[u], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < NBT; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S[soff(r0[u] + lq + 4 * r) + c0[u] + ln] = acc[u][r];
+    };
     if (wave == 0) {
       if (jb + 1 < LEAF / SB) {
         {  // the 16 rows of the next diagonal block, four lanes per row
@@ -397,6 +439,12 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
         LEAF_STAMP(6);
         factor_diag(jb + 1);
         LEAF_STAMP(7);
+        if (n0 > 0) {  // every row of column block jb must be solved before its tiles can be updated
+          while (sync_w[1] < 3 * (jb + 1)) __builtin_amdgcn_s_sleep(1);
+          wave_lds_fence();
+          if (n0 == 3) batch(std::integral_constant<int, 3>(), nh, 1);
+          else batch(std::integral_constant<int, 2>(), nh, 1);
+        }
       }
     } else {
       const int t = tid - 64;
@@ -428,51 +476,12 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
       }
       LEAF_STAMP1(8);
       LEAF_STAMP1(9);
-      // trailing tiles (tr, tc), 1 <= tr < q, tc <= tr, dealt round-robin to waves 1..3 (tile (0,0) belongs to wave 0)
-      // and processed three at a time with their MFMAs interleaved: a chain of four dependent fp64 MFMAs takes ~1k
-      // cycles, three independent chains take the same (these waves, not wave 0, were the long pole of the early
-      // iterations: 9 tiles each at jb = 0)
-      const int q = LEAF / SB - 1 - jb;  // trailing tiles per dimension
-      const int ntile = q * (q + 1) / 2 - 1;
-      const int ln = lane & 15, lq = lane >> 4;
-      auto tile_of = [&](int e, int& r0, int& c0) {  // e-th trailing tile (tile (0,0) excluded) -> first row / column
-        int tr = 1;
-        while ((tr + 1) * (tr + 2) / 2 <= e + 1) ++tr;
-        const int tc = e + 1 - tr * (tr + 1) / 2;
-        r0 = j0 + SB + 16 * tr;
-        c0 = j0 + SB + 16 * tc;
-      };
-      const int cnt = ntile > wave - 1 ? (ntile - (wave - 1) + 2) / 3 : 0;  // this wave's tiles: e = wave-1, wave+2, ...
+      const int cnt = nh > wave - 1 ? (nh - (wave - 1) + 2) / 3 : 0;  // this wave's tiles: e = wave-1, wave+2, ...
       int done = 0;
-      for (; done + 3 <= cnt; done += 3) {  // full batches: no predicates, one scheduling region
-        double av[3][4], bv[3][4];
-        double4_t acc[3];
-        int r0[3], c0[3];
-#pragma unroll
-        for (int u = 0; u < 3; ++u) {
-          tile_of(wave - 1 + 3 * (done + u), r0[u], c0[u]);
-#pragma unroll
-          for (int s4 = 0; s4 < 4; ++s4) {
-            av[u][s4] = S[soff(r0[u] + ln) + j0 + 4 * s4 + lq];
-            bv[u][s4] = S[soff(c0[u] + ln) + j0 + 4 * s4 + lq];
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[u][r] = S[soff(r0[u] + lq + 4 * r) + c0[u] + ln];
-        }
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-          for (int u = 0; u < 3; ++u) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[u][s4], bv[u][s4], acc[u], 0, 0, 0);
-#pragma unroll
-        for (int u = 0; u < 3; ++u)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) S[soff(r0[u] + lq + 4 * r) + c0[u] + ln] = acc[u][r];
-      }
-      for (; done < cnt; ++done) {
-        int r0, c0;
-        tile_of(wave - 1 + 3 * done, r0, c0);
-        update_tile(j0, r0, c0);
-      }
+      for (; done + 4 <= cnt; done += 4) batch(std::integral_constant<int, 4>(), wave - 1 + 3 * done, 3);
+      if (cnt - done == 3) batch(std::integral_constant<int, 3>(), wave - 1 + 3 * done, 3);
+      else if (cnt - done == 2) batch(std::integral_constant<int, 2>(), wave - 1 + 3 * done, 3);
+      else if (cnt - done == 1) batch(std::integral_constant<int, 1>(), wave - 1 + 3 * done, 3);
       LEAF_STAMP1(10);
     }
     __syncthreads();

@@ -449,19 +449,30 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
     } else {
       const int t = tid - 64;
       const int nrest = LEAF - j0 - 2 * SB;  // rows j0+32 .. 127
+      LEAF_STAMP1(15);  // wait at the previous iteration's barrier
       if (t < nrest) solve_row(jb, j0 + 2 * SB + t);
+      LEAF_STAMP1(9);   // solve_row
       // column block cb is final for rows >= 16 cb once iteration cb's rows are solved: 8 pieces of 16 B per row go to
       // memory.  Block jb - 1 is streamed here, in the time these waves would otherwise spin waiting for wave 0's rows.
-      auto stream_out = [&](int cb) {
-        const int c0 = cb * SB;
-        for (int it = t; it < (LEAF - c0) * 8; it += 192) {
+      auto stream_out = [&](int cb) {  // at most 6 pieces per thread: all LDS reads first, then the stores (one round trip)
+        const int c0 = cb * SB, npiece = (LEAF - c0) * 8;
+        double2_t v[6];
+        bool full[6], half[6];
+        double* dst[6];
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+          const int it = t + 192 * u;
           const int r = c0 + (it >> 3), c2 = c0 + 2 * (it & 7);
-          if (c2 <= r) {
-            const double2_t v = *reinterpret_cast<const double2_t*>(S + soff(r) + c2);
-            double* dst = Ablk + (long)r * lda + c2;
-            if (c2 + 1 <= r) *reinterpret_cast<double2_t*>(dst) = v;
-            else dst[0] = v.x;
-          }
+          const bool in = it < npiece && c2 <= r;
+          full[u] = in && c2 + 1 <= r;
+          half[u] = in && c2 + 1 > r;
+          dst[u] = Ablk + (long)r * lda + c2;
+          if (in) v[u] = *reinterpret_cast<const double2_t*>(S + soff(r) + c2);
+        }
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+          if (full[u]) *reinterpret_cast<double2_t*>(dst[u]) = v[u];
+          else if (half[u]) dst[u][0] = v[u].x;
         }
       };
       if (jb + 1 < LEAF / SB) {
@@ -474,8 +485,7 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
         stream_out(jb - 1);
         stream_out(jb);
       }
-      LEAF_STAMP1(8);
-      LEAF_STAMP1(9);
+      LEAF_STAMP1(8);   // arrive, stream-out, spin for wave 0's rows and the other helpers
       const int cnt = nh > wave - 1 ? (nh - (wave - 1) + 2) / 3 : 0;  // this wave's tiles: e = wave-1, wave+2, ...
       int done = 0;
       for (; done + 4 <= cnt; done += 4) batch(std::integral_constant<int, 4>(), wave - 1 + 3 * done, 3);

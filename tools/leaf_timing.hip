@@ -27,7 +27,7 @@ int main() {
   }
   unsigned long long st[16]; hipMemcpyFromSymbol(st, HIP_SYMBOL(g_leaf_stamps), sizeof(st));
   printf("inverse (thread 0): dinv compute %llu | dinv write+sync %llu | stage A (3 levels, incl. previous syncs) %llu | stage B %llu | rest -> slot dinv\n", st[11], st[12], st[13], st[14]);
-  printf("wave 1 cycles: solve+midsync %llu | stream-out %llu | trailing %llu | P1 dinv %llu | P2 %llu | sync+P3 %llu | sync+P4 %llu | sync+P5 %llu\n", st[8], st[9], st[10], st[11], st[12], st[13], st[14], st[15]);
+  printf("wave 1 cycles: barrier wait %llu | solve_row %llu | arrive+stream-out+spin %llu | trailing %llu\n", st[15], st[9], st[8], st[10]);
   printf("leaf kernel %.1f us; cycles: load %llu | A(diag) %llu | B(trsm) %llu | C(update) %llu | store %llu | dinv %llu || w0: tile %llu factor %llu\n", best * 1e3, st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7]);
   hipMemcpy(A.data(), dA, A.size() * 8, hipMemcpyDeviceToHost);
   // check L L^T = A0

@@ -319,9 +319,10 @@ static hipError_t hand_off(mi_gp_handle* h, hipStream_t from, hipStream_t to) {
   return hipStreamWaitEvent(to, ev, 0);
 }
 
-// Below this many tile columns one stream is faster than two (measured, plain launches: N = 2048 1.03 vs 1.13 ms,
-// N = 4096 2.46 vs 2.48 ms, N = 8192 7.09 vs 6.45 ms): the cross-stream hand-offs cost more than the overlap returns.
-constexpr int LOOKAHEAD_MIN_TILES = 40;
+// Below this many tile columns one stream is faster than two: the cross-stream hand-offs cost more than the overlap
+// returns (one stream vs two, end of round 2: N = 2048 0.94 vs 1.01 ms, N = 4096 2.235 vs 2.252, N = 4608 2.513 vs 2.472,
+// N = 5120 2.849 vs 2.820, N = 6144 3.81 vs 3.59, N = 8192 6.35 vs 5.67).
+constexpr int LOOKAHEAD_MIN_TILES = 36;
 
 static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int ntc) {
   const bool la = h->lookahead == 2 || (h->lookahead == 1 && ntc >= LOOKAHEAD_MIN_TILES);

@@ -112,7 +112,7 @@ int mi_gp_predict_grad(mi_gp_handle* h, const double* Xnew_dev, int m, double* w
 
 /* tuning knobs (benchmarks / A-B tests), ALL per handle -- nothing here is process-wide:
  *   0  look-ahead: factor the next super-panel on a second stream while the trailing update runs; 0 never, 1 by size
- *      (default: from 40 tile columns = N > 4992 on, where the overlap beats the cross-stream hand-offs), 2 always
+ *      (default: from 36 tile columns = N > 4480 on, where the overlap beats the cross-stream hand-offs), 2 always
  *   2  super-panel width in 128-column tiles (default 0 = by trailing size, options 4-6)
  *   4-6  trailing sizes (tile columns) above which the super-panel is 16 / 8 / 4 tiles wide (below the last: 2);
  *        defaults: never 16, else 8

@@ -137,7 +137,7 @@ class MiGP:
 
     def update_data(self, X=None, y=None):
         """Overwrite the resident inputs / outputs in place (same shapes): warped data change at every
-        posterior evaluation while the buffers, the handle and its captured graphs stay."""
+        posterior evaluation while the buffers, the handle and its streams stay."""
         self._factored_ok = False
         with torch.cuda.device(self.dev):
             if X is not None:

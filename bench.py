@@ -235,6 +235,8 @@ def main():
     ap.add_argument("--grad", action="store_true", help="with --sharded: time LML + gradient (sharded K^-1) instead of the LML")
     ap.add_argument("--grad-steps", type=int, default=5, help="LML + gradient evaluations timed after the LML region (0: skip)")
     ap.add_argument("--no-lookahead", action="store_true", help="disable the look-ahead stream everywhere (profiling aid)")
+    ap.add_argument("--chains-per-gpu", type=int, default=3,
+                    help="extra record: this many handles evaluated side by side on every GPU (independent chains; 0/1: skip)")
     args = ap.parse_args()
 
     env_world = os.environ.get("WORLD_SIZE")
@@ -323,6 +325,47 @@ def main():
                     "algorithmic_flops": "N^3 (factor N^3/3 + L^-T N^3/3 + K^-1 = U U^T N^3/3)",
                     "tflops_whole_eval": N ** 3 / tg * 1e-12, "frac_of_fp64_peak": N ** 3 / tg * 1e-12 / FP64_PEAK_TFLOPS}
 
+    # Independent chains sharing a GPU (how GPMCMC.fit(method='mcmc_*') schedules more chains than GPUs): K handles
+    # driven by K host threads; an evaluation is bound by the serial panel chain for part of its time, a second and third
+    # one fill the idle CUs.  Extra record only: `value` above stays one chain per GPU (its ms_per_step is the latency a
+    # single MAP optimisation or chain sees).
+    conc_rec = None
+    if args.chains_per_gpu > 1:
+        import threading
+        K = args.chains_per_gpu
+        others = [MiGP(X, y, args.kernel, device=local_rank, panel_tiles=args.panel_tiles, need_grad=False) for _ in range(K - 1)]
+        lanes = [gp] + others
+        csteps = max(2, min(args.steps, 8))
+        for h in lanes:
+            h.lml(thetas[0])
+
+        def lane_work(h, off):
+            for i in range(csteps):
+                v = h.lml(thetas[(off + i) % len(thetas)])
+                assert np.isfinite(v)
+
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        tc = time.perf_counter()
+        ths = [threading.Thread(target=lane_work, args=(h, j)) for j, h in enumerate(lanes)]
+        for th_ in ths:
+            th_.start()
+        for th_ in ths:
+            th_.join()
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        tc = torch.tensor([time.perf_counter() - tc], dtype=torch.float64, device=dev)
+        dist.all_reduce(tc, op=dist.ReduceOp.MAX)
+        tc = float(tc.item())
+        conc_rec = {"chains_per_gpu": K, "evals_per_s": world * K * csteps / tc, "steps_per_chain": csteps,
+                    "ms_per_round_of_K": tc / csteps * 1e3,
+                    "tflops_whole_eval_per_gpu": K * csteps * (N ** 3 / 3.0) / tc * 1e-12,
+                    "frac_of_fp64_peak": K * csteps * (N ** 3 / 3.0) / tc * 1e-12 / FP64_PEAK_TFLOPS}
+        for h in others:
+            h.close()
+        del others, lanes
+        torch.cuda.empty_cache()
+
     # Roofline pass (rank 0): the same evaluations again with HIP events on the handle's own stream
     # around every phase and every GEMM launch.  Look-ahead is switched off for this pass so that
     # the dominant kernel runs alone on the chip and its launch durations are not inflated by the
@@ -385,6 +428,7 @@ def main():
             "cholesky_frac_of_peak_whole_eval": (N ** 3 / 3.0) / (elapsed / steps) * 1e-12 / FP64_PEAK_TFLOPS,
             "launch_mode": "plain launches, look-ahead on a second stream (hipGraph replay removed in round 2: see DESIGN.md)",
             "lml_grad": grad_rec,
+            "concurrent_chains": conc_rec,
             "roofline_pass": {"steps": rsteps, "lookahead": False,
                               "phase_ms": {"assemble": acc["assemble_ms"] / rsteps, "cholesky": acc["cholesky_ms"] / rsteps,
                                            "gemm_in_cholesky": acc["gemm_ms"] / rsteps}},

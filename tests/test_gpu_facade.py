@@ -65,6 +65,20 @@ def test_matern_noise_fit_train_test_and_change_model():
     assert np.sqrt(np.mean((g.predict(xt) - yt) ** 2)) < 2e-2
 
 
+def test_chains_sharing_a_gpu_run_concurrently_with_identical_draws():
+    # chains that share a device run on up to three handles at once (MCMC driver, gpmcmc.py:351); an evaluation is
+    # deterministic per handle, so every chain's draws must equal those of the one-handle, back-to-back schedule
+    out = {}
+    for k in (1, 3):
+        g, _ = _tutorial_gp(kernel="RBF", noise=True, n=40, seed=3)
+        data = g.fit(method="mcmc_mean", return_data=True, draws=30, tune=30, chains=3, random_seed=5, chains_per_device=k)
+        out[k] = data
+    assert out[1].posterior["l"].shape == (3, 30, 2)
+    for name in ("l", "kv", "gv"):
+        assert np.array_equal(out[1].posterior[name], out[3].posterior[name]), name
+    assert np.array_equal(out[1].sample_stats["lp"], out[3].sample_stats["lp"])
+
+
 def test_mcmc_modes_short_chains():
     g, fun = _tutorial_gp(kernel="RBF", noise=True, n=40, seed=3)
     data = g.fit(method="mcmc_mean", return_data=True, draws=60, tune=60, chains=2, random_seed=1)

@@ -14,9 +14,9 @@ cd /tmp && export TMPDIR=/tmp
 stats() {  # dir -> csv copy
   f=$(find $OUT/$1 -name "*kernel_stats.csv" | head -1); cp "$f" $OUT/$2
 }
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p_${tag}_bench -- python3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-sharded > $OUT/p_${tag}_bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p_${tag}_bench -- python3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-sharded --chains-per-gpu 0 > $OUT/p_${tag}_bench.log 2>&1
 grep '"metric"' $OUT/p_${tag}_bench.log > $OUT/${tag}_bench_line_profiled.json; stats p_${tag}_bench ${tag}_kernel_stats_bench.csv
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p_${tag}_nola -- python3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-sharded --no-lookahead --grad-steps 0 > $OUT/p_${tag}_nola.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p_${tag}_nola -- python3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-sharded --chains-per-gpu 0 --no-lookahead --grad-steps 0 > $OUT/p_${tag}_nola.log 2>&1
 grep '"metric"' $OUT/p_${tag}_nola.log > $OUT/${tag}_bench_line_nolookahead.json; stats p_${tag}_nola ${tag}_kernel_stats_bench_nolookahead.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p_${tag}_grad -- python3 $ROOT/tools/trace_n.py 16384 16 grad > $OUT/p_${tag}_grad.log 2>&1
 stats p_${tag}_grad ${tag}_kernel_stats_lml_grad_n16384.csv
@@ -27,7 +27,7 @@ for n in 4096 8192; do
   stats p_${tag}_n$n ${tag}_kernel_stats_lml_n$n.csv
 done
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -- python3 $ROOT/bench.py --steps 2 --warmup 1 --roofline-steps 1 --no-cpu-baseline --no-sharded --grad-steps 0 > $OUT/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -- python3 $ROOT/bench.py --steps 2 --warmup 1 --roofline-steps 1 --no-cpu-baseline --no-sharded --chains-per-gpu 0 --grad-steps 0 > $OUT/pmc_$c.log 2>&1
 done
 python3 $ROOT/tools/pmc_traffic.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/gemm_traffic.json
 for f in $OUT/p_${tag}_grad.log $OUT/p_${tag}_pred.log; do tail -n 2 $f | cut -c1-200; done

@@ -292,9 +292,18 @@ static hipError_t chol_panel(mi_gp_handle* h, double* A, long lda, int ntr, int 
 // super-panel width (128-column tiles) for a trailing matrix of `rem` tile columns: wide panels while
 // the trailing update is long enough to hide their factorisation (k = 1024 runs the GEMM at ~64
 // TFLOP/s instead of ~57 at k = 512), narrower ones once the panel chain is the critical path
-static int pick_w(const mi_gp_handle* h, int rem) {
+// Super-panel width in tiles for `rem` remaining tile columns.  `cap` (0: none) limits the size-derived width: the
+// two-stream driver factors problems of up to 64 tile columns in 4-tile super-panels (8 vs 4, interleaved A/B at the end
+// of round 2: N = 4608 2.510 vs 2.475 ms, 5120 2.840 vs 2.725, 6144 3.602 vs 3.504, 7168 4.628 vs 4.538, 8192 5.742 vs
+// 5.678; 9216 equal, 10240 9.05 vs 9.14, 16384 27.4 vs 28.8 -- and 4-tile panels only for the last 52 / 64 columns of
+// larger problems lose 1-2 %).  An explicit panel_tiles (option 2) overrides everything.
+constexpr int NARROW_PANELS_MAX_TILES = 64;
+static int pick_w(const mi_gp_handle* h, int rem, int cap) {
   int W = h->cfg.panel_tiles;
-  if (W <= 0) W = (rem > h->w_thr[0]) ? 16 : (rem > h->w_thr[1]) ? 8 : (rem > h->w_thr[2]) ? 4 : 2;
+  if (W <= 0) {
+    W = (rem > h->w_thr[0]) ? 16 : (rem > h->w_thr[1]) ? 8 : (rem > h->w_thr[2]) ? 4 : 2;
+    if (cap > 0 && W > cap) W = cap;
+  }
   return rem < W ? rem : W;
 }
 
@@ -332,13 +341,14 @@ static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int nt
   h->ev_next = 0;
   h->wait_col = -1;
   if (P != T) CKE(hand_off(h, T, P));  // panel stream starts after everything already queued on the main stream (assembly)
-  int w = pick_w(h, ntc);
+  const int wcap = (P != T && ntc <= NARROW_PANELS_MAX_TILES) ? 4 : 0;
+  int w = pick_w(h, ntc, wcap);
   CKE(chol_panel(h, A, lda, ntr, 0, w, P));
   for (int J = 0; J < ntc;) {
     const int n1 = J + w;  // first tile column right of this super-panel
     if (P != T) CKE(hand_off(h, P, T));  // the main stream may read super-panel J from here on
     if (n1 >= ntc) break;
-    const int wn = pick_w(h, ntc - n1);
+    const int wn = pick_w(h, ntc - n1, wcap);
     if (P != T) {
       // (a1) the next super-panel's FIRST tile column on the panel stream itself: the chain goes on to its leaf without
       //      waiting for the other wn - 1 columns (round 1 updated all wn columns on the main stream first: 40-80 us on

@@ -115,12 +115,13 @@ int mi_gp_predict_grad(mi_gp_handle* h, const double* Xnew_dev, int m, double* w
  *      (default: from 36 tile columns = N > 4480 on, where the overlap beats the cross-stream hand-offs), 2 always
  *   2  super-panel width in 128-column tiles (default 0 = by trailing size, options 4-6)
  *   4-6  trailing sizes (tile columns) above which the super-panel is 16 / 8 / 4 tiles wide (below the last: 2);
- *        defaults: never 16, else 8
+ *        defaults: never 16, else 8; with look-ahead active, problems of up to 64 tile columns use at most 4
  *   7  GEMM launches with fewer 128x128 tiles than this run on 64x64 tiles (default 1024)
  *   8  trailing size at or below which look-ahead bulk updates run one workgroup per CU (default: always)
  *   14 band height (tile rows) of the band-column-major tile order of uniform-k trapezoid launches (default 8, 0 = row-major)
  *   16 panel-stream GEMM launches raise their waves' issue priority (s_setprio 3) against the bulk update's (default 1)
- * 0, 8, 14 and 16 only change scheduling (bit-identical results); 2, 4-7 regroup sums (agreement to rounding).
+ * 8, 14 and 16 only change scheduling (bit-identical results); 2, 4-7 regroup sums (agreement to rounding), and so does 0 where
+ * it changes the super-panel width (36 to 64 tile columns).
  * Unknown ids return -1.  (Round 1's options 1, 3, 9-13 -- GEMM variants, hipGraph replay, persistent bulk kernels,
  * exclusive leaf, fused leaf + strip -- are gone with the code they selected.) */
 int mi_gp_set_option(mi_gp_handle* h, int what, int value);

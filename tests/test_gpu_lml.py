@@ -193,8 +193,11 @@ def test_tuning_options_do_not_change_results():
     X, y = orc.synth_problem(3000, 6, seed=2)
     theta = orc.synth_theta(6)
     gp = MiGP(X, y, "Matern52", need_grad=False)
+    ref0 = gp.lml(theta)
+    gp.set_option(2, 8)  # pin the super-panel width: by default it also depends on whether look-ahead is active (option 0)
     ref = gp.lml(theta)
-    for what, value in [(0, 0), (0, 2), (8, 1 << 20), (8, 0), (14, 0), (14, 4), (16, 0), (16, 1), (7, 0), (7, 100000), (2, 2), (2, 8)]:
+    assert abs(ref - ref0) <= 1e-11 * abs(ref0)
+    for what, value in [(0, 0), (0, 2), (8, 1 << 20), (8, 0), (14, 0), (14, 4), (16, 0), (16, 1), (7, 0), (7, 100000), (2, 2), (2, 4), (2, 8)]:
         gp.set_option(what, value)
         v = gp.lml(theta)
         if what in (2, 7):  # the super-panel width regroups the k-sums of the updates, the tile size their MFMA order
@@ -202,6 +205,9 @@ def test_tuning_options_do_not_change_results():
         else:               # pure scheduling knobs: same arithmetic in the same order per tile, bit-identical
             assert v == ref, (what, value, v, ref)
         assert gp.lml(theta) == v  # and again
+    gp.set_option(2, 0)  # default width again: forced look-ahead narrows the super-panels of a problem this small
+    gp.set_option(0, 2)
+    assert abs(gp.lml(theta) - ref) <= 1e-11 * abs(ref)
     for gone in (1, 3, 9, 10, 11, 12, 13, 15):  # round-1 experiments: GEMM variants, graph replay, persistent bulk, exclusive leaf, fused leaf + strip
         with pytest.raises(RuntimeError):
             gp.set_option(gone, 0)

@@ -215,6 +215,31 @@ struct DinvStep<16> {
   static __device__ __forceinline__ void run(double (&)[16], double (&)[16], const double (&)[16], const double (&)[16], int) {}
 };
 
+// Trailing 16x16 tiles of the leaf in block coordinates (r >= c >= 1; tile (1,1) is wave 0's from the start), in dealing
+// order: tile i belongs to helper wave i % 3 (waves 1..3), register slot i / 3 -- nine tiles per wave, and every
+// iteration's live tiles are split within one tile of evenly.  A tile lives in its wave's REGISTERS from the start of the
+// loop until its last rank-16 update (left-looking accumulation: tile (r,c) -= X(r,k) X(c,k)^T for k = 0 .. c-1, the
+// diagonal tiles up to k = c-2, after which wave 0 takes them over) and is written to the LDS image exactly once.
+namespace lt {
+constexpr int NTT = 27;
+constexpr int TR[NTT] = {2, 3, 4, 5, 6, 7, 2, 3, 4, 5, 6, 7, 3, 4, 5, 6, 7, 4, 5, 6, 7, 5, 6, 7, 6, 7, 7};
+constexpr int TC[NTT] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 6, 6, 7};
+constexpr bool live(int i, int jb) { return TR[i] == TC[i] ? jb <= TC[i] - 2 : jb <= TC[i] - 1; }
+constexpr bool last(int i, int jb) { return TR[i] == TC[i] ? jb == TC[i] - 2 : jb == TC[i] - 1; }
+constexpr bool needs(int w, int jb, int b) {  // does wave w read block row b of column block jb as an operand?
+  for (int s = 0; s < 9; ++s)
+    if (live(3 * s + w, jb) && (TR[3 * s + w] == b || TC[3 * s + w] == b)) return true;
+  return false;
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>());
+    static_for<I + 1, N>(f);
+  }
+}
+}  // namespace lt
+
 // info: 0 = ok, else 1-based global index of the first non-positive (or NaN) pivot (atomicMin'd).
 //
 // Structure per 16-column block jb of the 128x128 leaf (all of it LDS resident):
@@ -361,56 +386,64 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
   if (wave == 0) factor_diag(0);
   __syncthreads();
   LEAF_STAMP(1);
+  // Register-resident trailing tiles of waves 1..3 (see namespace lt).  Per iteration a wave reads one operand set
+  // (4 doubles per lane) per block row it touches -- the same registers serve as the MFMA A operand of the tiles in that
+  // block row and as the B operand of the tiles in that block column -- and issues its live tiles' MFMAs interleaved
+  // (up to nine independent accumulators: full issue rate).  Round 2 until here: every tile went LDS -> registers -> LDS
+  // in every iteration, three or four at a time (0.7k cycles per tile; 12 LDS accesses per lane and tile instead of ~3).
+  double4_t tacc[9];
+  auto trailing = [&](auto JBc, auto Wc) {
+    constexpr int JB = decltype(JBc)::value, W = decltype(Wc)::value;
+    double op[8][4];
+    lt::static_for<1, 8>([&](auto Bc) {
+      constexpr int B = decltype(Bc)::value;
+      if constexpr (lt::needs(W, JB, B)) {
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) op[B][s4] = S[soff(16 * B + nn) + 16 * JB + 4 * s4 + kq];
+      }
+    });
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+      lt::static_for<0, 9>([&](auto Sc) {
+        constexpr int I = 3 * decltype(Sc)::value + W;
+        if constexpr (lt::live(I, JB))
+          tacc[decltype(Sc)::value] = __builtin_amdgcn_mfma_f64_16x16x4f64(-op[lt::TR[I]][s4], op[lt::TC[I]][s4], tacc[decltype(Sc)::value], 0, 0, 0);
+      });
+    lt::static_for<0, 9>([&](auto Sc) {
+      constexpr int I = 3 * decltype(Sc)::value + W;
+      if constexpr (lt::last(I, JB)) put(tacc[decltype(Sc)::value], lt::TR[I], lt::TC[I]);
+    });
+  };
+  auto trailing_all = [&](auto Wc, int jb) {
+    switch (jb) {
+      case 0: trailing(std::integral_constant<int, 0>(), Wc); break;
+      case 1: trailing(std::integral_constant<int, 1>(), Wc); break;
+      case 2: trailing(std::integral_constant<int, 2>(), Wc); break;
+      case 3: trailing(std::integral_constant<int, 3>(), Wc); break;
+      case 4: trailing(std::integral_constant<int, 4>(), Wc); break;
+      case 5: trailing(std::integral_constant<int, 5>(), Wc); break;
+      default: break;
+    }
+  };
+  auto load_tiles = [&](auto Wc) {
+    constexpr int W = decltype(Wc)::value;
+    lt::static_for<0, 9>([&](auto Sc) {
+      constexpr int I = 3 * decltype(Sc)::value + W;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tacc[decltype(Sc)::value][r] = S[soff(16 * lt::TR[I] + kq + 4 * r) + 16 * lt::TC[I] + nn];
+    });
+  };
   // Per 16-column block jb, after the diagonal sub-block jb has been factored:
   //   wave 0     : solves the 16 rows of the NEXT diagonal block, publishes them, updates the next diagonal
   //                tile and factors it (the serial chain of the leaf);
   //   waves 1..3 : solve the remaining rows, meet each other and wave 0's rows through two LDS words, apply
   //                the rank-16 MFMA update to every other trailing tile and stream column block jb out.
-  for (int jb = 0; jb < LEAF / SB; ++jb) {
-    const int j0 = jb * SB;
-    // trailing tiles (tr, tc), 1 <= tr < q, tc <= tr, of this iteration's rank-16 update (tile (0,0), the next diagonal
-    // block, belongs to wave 0's chain).  They are processed up to FOUR at a time with their MFMAs interleaved: a chain of
-    // four dependent fp64 MFMAs takes ~1k cycles, and so do four independent chains (16 x 64 issue cycles).  The first
-    // nh tiles are dealt round-robin to waves 1..3; in the two longest iterations wave 0 takes the last n0 tiles after
-    // its chain instead of idling (jb = 0: 27 tiles = 3 x 8 + 3, jb = 1: 20 = 3 x 6 + 2: two rounds per wave, not three).
-    const int q = LEAF / SB - 1 - jb;  // trailing tiles per dimension
-    const int ntile = q * (q + 1) / 2 - 1;
-    const int n0 = jb == 0 ? 3 : (jb <= 2 ? 2 : 0);
-    const int nh = ntile - n0;
-    const int ln = lane & 15, lq = lane >> 4;
-    auto tile_of = [&](int e, int& r0, int& c0) {  // e-th trailing tile (tile (0,0) excluded) -> first row / column
-      int tr = 1;
-      while ((tr + 1) * (tr + 2) / 2 <= e + 1) ++tr;
-      const int tc = e + 1 - tr * (tr + 1) / 2;
-      r0 = j0 + SB + 16 * tr;
-      c0 = j0 + SB + 16 * tc;
-    };
-    auto batch = [&](auto NBc, int e0, int estride) {  // tiles e0, e0 + estride, ...: no predicates, one scheduling region
-      constexpr int NBT = decltype(NBc)::value;
-      double av[NBT][4], bv[NBT][4];
-      double4_t acc[NBT];
-      int r0[NBT], c0[NBT];
-#pragma unroll
-      for (int u = 0; u < NBT; ++u) {
-        tile_of(e0 + estride * u, r0[u], c0[u]);
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-          av[u][s4] = S[soff(r0[u] + ln) + j0 + 4 * s4 + lq];
-          bv[u][s4] = S[soff(c0[u] + ln) + j0 + 4 * s4 + lq];
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[u][r] = S[soff(r0[u] + lq + 4 * r) + c0[u] + ln];
-      }
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-        for (int u = 0; u < NBT; ++u) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[u][s4], bv[u][s4], acc[u], 0, 0, 0);
-#pragma unroll
-      for (int u = 0; u < NBT; ++u)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) S[soff(r0[u] + lq + 4 * r) + c0[u] + ln] = acc[u][r];
-    };
-    if (wave == 0) {
+  // Two loops, one per wave role, with the same number of workgroup barriers (s_barrier counts waves, not code
+  // locations): the register-resident tiles of waves 1..3 and the solve / factor state of wave 0 then never share a
+  // live range (in one loop body the kernel needed 256 VGPRs + 204 AGPRs of spill space).
+  if (wave == 0) {
+    for (int jb = 0; jb < LEAF / SB; ++jb) {
+      const int j0 = jb * SB;
       if (jb + 1 < LEAF / SB) {
         {  // the 16 rows of the next diagonal block, four lanes per row
           const int g = lane & 3;
@@ -439,14 +472,18 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
         LEAF_STAMP(6);
         factor_diag(jb + 1);
         LEAF_STAMP(7);
-        if (n0 > 0) {  // every row of column block jb must be solved before its tiles can be updated
-          while (sync_w[1] < 3 * (jb + 1)) __builtin_amdgcn_s_sleep(1);
-          wave_lds_fence();
-          if (n0 == 3) batch(std::integral_constant<int, 3>(), nh, 1);
-          else batch(std::integral_constant<int, 2>(), nh, 1);
-        }
       }
-    } else {
+      __syncthreads();
+      LEAF_STAMP(3);
+    }
+  } else {
+    if (wave == 1) load_tiles(std::integral_constant<int, 0>());
+    else if (wave == 2) load_tiles(std::integral_constant<int, 1>());
+    else load_tiles(std::integral_constant<int, 2>());
+#pragma unroll  // fully: every copy sees a constant jb, the tile accumulators have plain live ranges (no loop-carried phis
+                // through a switch: that form cost 200 registers of copies and moved the accumulators to AGPRs)
+    for (int jb = 0; jb < LEAF / SB; ++jb) {
+      const int j0 = jb * SB;
       const int t = tid - 64;
       const int nrest = LEAF - j0 - 2 * SB;  // rows j0+32 .. 127
       LEAF_STAMP1(15);  // wait at the previous iteration's barrier
@@ -486,16 +523,12 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
         stream_out(jb);
       }
       LEAF_STAMP1(8);   // arrive, stream-out, spin for wave 0's rows and the other helpers
-      const int cnt = nh > wave - 1 ? (nh - (wave - 1) + 2) / 3 : 0;  // this wave's tiles: e = wave-1, wave+2, ...
-      int done = 0;
-      for (; done + 4 <= cnt; done += 4) batch(std::integral_constant<int, 4>(), wave - 1 + 3 * done, 3);
-      if (cnt - done == 3) batch(std::integral_constant<int, 3>(), wave - 1 + 3 * done, 3);
-      else if (cnt - done == 2) batch(std::integral_constant<int, 2>(), wave - 1 + 3 * done, 3);
-      else if (cnt - done == 1) batch(std::integral_constant<int, 1>(), wave - 1 + 3 * done, 3);
+      if (wave == 1) trailing_all(std::integral_constant<int, 0>(), jb);
+      else if (wave == 2) trailing_all(std::integral_constant<int, 1>(), jb);
+      else trailing_all(std::integral_constant<int, 2>(), jb);
       LEAF_STAMP1(10);
+      __syncthreads();
     }
-    __syncthreads();
-    LEAF_STAMP(3);
   }
   LEAF_STAMP(4);
   // ---- M = L^-1 (128x128, lower triangular) in place of L in LDS, streamed to `minv` (row-major, ld 128).

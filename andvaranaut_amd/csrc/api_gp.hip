@@ -388,13 +388,16 @@ static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int nt
 // up in K_dev, beta = L^-1 y in row np), reduction.
 static int enqueue_factor(mi_gp_handle* h, int noise_form, bool prof) {
   if (prof) (void)hipEventRecord(h->ev[0], h->stream);
+  // first kernel of the evaluation: y rows, the bad-pivot word, and theta from the pinned host buffer to theta_dev
+  HCK(launch_set_yrows(h->buf.K_dev, h->buf.lda, h->np, h->np, h->buf.y_dev, h->n, h->stream, h->info_dev, h->theta_host,
+                       h->theta_dev, h->ntheta), "set_yrows");
   HCK(launch_assemble(h->spec, h->theta_dev, h->buf.X_dev, h->n, h->buf.X_dev, h->n, h->buf.K_dev, h->buf.lda, h->np,
                       h->np, 1, noise_form, h->stream, 0, h->diag_dev), "assemble");
-  HCK(launch_set_yrows(h->buf.K_dev, h->buf.lda, h->np, h->np, h->buf.y_dev, h->n, h->stream, h->info_dev), "set_yrows");
   if (prof) (void)hipEventRecord(h->ev[1], h->stream);
   HCK(cholesky(h, h->buf.K_dev, h->buf.lda, h->ntc + 1, h->ntc), "cholesky");
   if (prof) (void)hipEventRecord(h->ev[2], h->stream);
-  HCK(launch_lml_reduce(h->buf.K_dev, h->buf.lda, h->buf.K_dev + (long)h->np * h->buf.lda, h->n, h->out_dev, h->stream, h->info_dev), "lml_reduce");
+  // the scalars go straight to the pinned host buffer (device-visible): no download launch behind the reduction
+  HCK(launch_lml_reduce(h->buf.K_dev, h->buf.lda, h->buf.K_dev + (long)h->np * h->buf.lda, h->n, h->out_host, h->stream, h->info_dev), "lml_reduce");
   if (prof) (void)hipEventRecord(h->ev[3], h->stream);
   return 0;
 }
@@ -403,7 +406,6 @@ static int enqueue_gradient(mi_gp_handle* h, bool prof);
 static hipError_t inverse_transpose(mi_gp_handle* h);
 
 static int download_results(mi_gp_handle* h, int what) {
-  HCK(hipMemcpyAsync(h->out_host, h->out_dev, sizeof(double) * 16, hipMemcpyDeviceToHost, h->stream), "out download");
   if (what == 2)
     HCK(hipMemcpyAsync(h->grad_host, h->grad_dev, sizeof(double) * h->ntheta, hipMemcpyDeviceToHost, h->stream), "grad download");
   return 0;
@@ -425,8 +427,7 @@ static int run_evaluation(mi_gp_handle* h, int what) {
   const bool prof = h->prof_level >= 1;
   h->gemm_ev_used = 0;
   h->gemm_flops_acc = 0.0;
-  HCK(hipMemcpyAsync(h->theta_dev, h->theta_host, sizeof(double) * h->ntheta, hipMemcpyHostToDevice, h->stream), "theta upload");
-  if (int r = enqueue_all(h, what, prof)) return r;
+  if (int r = enqueue_all(h, what, prof)) return r;  // theta travels inside the first kernel (set_yrows_kernel)
   return download_results(h, what);
 }
 

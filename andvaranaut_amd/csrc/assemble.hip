@@ -272,9 +272,14 @@ __global__ __launch_bounds__(256, (KID_STATIC >= 0 && KID_STATIC != KID_RATQUAD)
 
 // rows [row0, row0+128) x cols [0, cols_pad): zero, except row row0 = y^T (first n entries)
 __global__ void set_yrows_kernel(double* __restrict__ K, long ldk, int row0, int cols_pad,
-                                 const double* __restrict__ y, int n, int* __restrict__ info) {
+                                 const double* __restrict__ y, int n, int* __restrict__ info,
+                                 const double* __restrict__ theta_src, double* __restrict__ theta_dst, int ntheta) {
   // info (optional): the evaluation's bad-pivot word starts as "none" here (a memset less per evaluation)
   if (info && blockIdx.x == 0 && threadIdx.x == 0) info[0] = 0x7f7f7f7f;
+  // theta (optional): this evaluation's hyper-parameters travel from the handle's pinned host buffer to the device copy
+  // every later kernel reads -- a copy launch less per evaluation (this kernel runs first)
+  if (theta_src && blockIdx.x == 0)
+    for (int i = threadIdx.x; i < ntheta; i += blockDim.x) theta_dst[i] = theta_src[i];
   const long total = 128L * cols_pad;
   for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     const int r = (int)(e / cols_pad), c = (int)(e % cols_pad);
@@ -355,11 +360,11 @@ hipError_t launch_assemble(const KernSpec& spec, const double* theta, const doub
 }
 
 hipError_t launch_set_yrows(double* K, long ldk, int row0, int cols_pad, const double* y, int n, hipStream_t stream,
-                            int* info) {
+                            int* info, const double* theta_src, double* theta_dst, int ntheta) {
   const long total = 128L * cols_pad;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  set_yrows_kernel<<<blocks, 256, 0, stream>>>(K, ldk, row0, cols_pad, y, n, info);
+  set_yrows_kernel<<<blocks, 256, 0, stream>>>(K, ldk, row0, cols_pad, y, n, info, theta_src, theta_dst, ntheta);
   return hipGetLastError();
 }
 

@@ -61,7 +61,7 @@ hipError_t launch_assemble(const KernSpec& spec, const double* theta, const doub
 // (rectangular blocks of a distributed covariance); the default means "no diagonal" (cross-covariance).
 // info (optional): reset to 0x7f7f7f7f ("no bad pivot") by the same launch
 hipError_t launch_set_yrows(double* K, long ldk, int row0, int cols_pad, const double* y, int n, hipStream_t stream,
-                            int* info = nullptr);
+                            int* info = nullptr, const double* theta_src = nullptr, double* theta_dst = nullptr, int ntheta = 0);
 // info (optional): its first word is forwarded as out[3]
 hipError_t launch_lml_reduce(const double* L, long ld, const double* beta, int n, double* out, hipStream_t stream,
                              const int* info = nullptr);

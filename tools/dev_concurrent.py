@@ -8,7 +8,7 @@ N, d = int(sys.argv[1]), int(sys.argv[2])
 grad = len(sys.argv) > 3
 th = theta_sequence(d, 8, seed=0)
 reps = 20 if N <= 8192 else 8
-for T in (1, 2, 3, 4):
+for T in [int(t) for t in os.environ.get("HANDLES", "1,2,3,4").split(",")]:
     gps = []
     for t in range(T):
         X, y = synth_problem(N, d, seed=t)

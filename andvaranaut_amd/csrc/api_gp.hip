@@ -270,8 +270,10 @@ static hipError_t chol_panel(mi_gp_handle* h, double* A, long lda, int ntr, int 
     double* blk = A + (long)c0 * 128 * lda + (long)c0 * 128;
     double* dinv = h->dinv_dev + (size_t)c0 * MINV_ELEMS;
     const int m = (ntr - c0 - 1) * 128;
-    e = launch_potrf_leaf128(blk, lda, dinv, c0 * 128, h->info_dev, st);
-    if (e == hipSuccess) e = launch_trsm_strip128(dinv, blk + 128 * lda, lda, m, st);
+    // (the trapezoid's last tile row is the y^T block: below the last tile column there is nothing else, and the leaf
+    // solves that one row itself)
+    e = launch_potrf_leaf128(blk, lda, dinv, c0 * 128, h->info_dev, st, m == 128 ? blk + 128 * lda : nullptr);
+    if (e == hipSuccess && m > 128) e = launch_trsm_strip128(dinv, blk + 128 * lda, lda, m, st);
     if (e == hipSuccess && c0 == h->wait_col) {  // the super-panel's other columns are being updated on the main stream
       h->wait_col = -1;
       e = hipStreamWaitEvent(st, h->wait_ev, 0);

@@ -251,7 +251,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 //  (B) rows below: X = B L16^-T, one thread per row, column-oriented substitution in registers;
 //  (C) trailing update of the remaining lower tiles on fp64 MFMA (rank 16).
 __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, long lda, double* __restrict__ minv,
-                                                    int col0, int* __restrict__ info, double* smem) {
+                                                    int col0, int* __restrict__ info, double* smem, double* yrow) {
   double* S = smem;                     // packed lower block-trapezoid, see soff()
   double* LdT2 = smem + LEAF_ELEMS;     // [2][16][16]  LdT[k][c] = L16[c][k] of diagonal sub-block jb (buffer jb & 1)
   double* invd = LdT2 + 2 * SB * SB;    // [128] 1 / L[c][c]
@@ -630,14 +630,27 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
     __syncthreads();
   }
   LEAF_STAMP(5);
+  // Last tile column of an evaluation: the only rows below are the y^T row block (one non-zero row), so the forward
+  // solve of these 128 columns, beta = y M^T, is done here against the inverse that is still in LDS -- the strip launch
+  // for that block (6 us of launch and round trips for 16k flops) is skipped.
+  if (yrow != nullptr) {
+    if (tid < LEAF) invd[tid] = yrow[tid];
+    __syncthreads();
+    const int c = tid >> 1, half = tid & 1;
+    const double* mrow = S + soff(c);
+    double acc = 0.0;
+    for (int k = half; k <= c; k += 2) acc = __builtin_fma(mrow[k], invd[k], acc);
+    acc += __shfl_xor(acc, 1);
+    if (half == 0) yrow[c] = acc;
+  }
 }
 
 __global__ __launch_bounds__(256, 1) void potrf_leaf128_kernel(double* __restrict__ Ablk, long lda,
                                                                 double* __restrict__ minv, int col0,
-                                                                int* __restrict__ info) {
+                                                                int* __restrict__ info, double* yrow) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   __builtin_amdgcn_s_setprio(3);  // the leaf is the panel chain: win the issue arbitration against bulk GEMM waves on its CU
-  potrf_leaf128_body(Ablk, lda, minv, col0, info, smem);
+  potrf_leaf128_body(Ablk, lda, minv, col0, info, smem, yrow);
 }
 
 // X * L^T = B in place on B (m x 128, leading dimension ldb even, m multiple of 16 RG) as X = B * M^T with M = L^-1
@@ -742,8 +755,8 @@ hipError_t leaf_enable_lds() {
   return e;
 }
 
-hipError_t launch_potrf_leaf128(double* Ablk, long lda, double* minv, int col0, int* info, hipStream_t stream) {
-  potrf_leaf128_kernel<<<1, 256, LEAF_LDS_BYTES, stream>>>(Ablk, lda, minv, col0, info);
+hipError_t launch_potrf_leaf128(double* Ablk, long lda, double* minv, int col0, int* info, hipStream_t stream, double* yrow) {
+  potrf_leaf128_kernel<<<1, 256, LEAF_LDS_BYTES, stream>>>(Ablk, lda, minv, col0, info, yrow);
   return hipGetLastError();
 }
 

@@ -36,7 +36,9 @@ constexpr int MINV_ELEMS = 128 * 128;  // doubles per leaf inverse
 // in-place lower Cholesky of one 128x128 diagonal block; minv receives M = L^-1 (row-major 128 x 128, lower triangular,
 // zeros above the diagonal inside the diagonal 16x16 tiles; the tiles above the block diagonal are not written and
 // never read); *info gets atomicMin(col0 + j + 1) on a bad pivot.
-hipError_t launch_potrf_leaf128(double* Ablk, long lda, double* minv, int col0, int* info, hipStream_t stream);
+// yrow (optional): row 0 of the 128-row block right below Ablk, solved in place against the leaf's inverse (beta = y M^T)
+hipError_t launch_potrf_leaf128(double* Ablk, long lda, double* minv, int col0, int* info, hipStream_t stream,
+                                double* yrow = nullptr);
 // X * L^T = B in place on the m x 128 panel B (m multiple of 16, ldb even) as X = B * M^T with the leaf's inverse M.
 hipError_t launch_trsm_strip128(const double* minv, double* B, long ldb, int m, hipStream_t stream);
 // batched form: pair b uses minv + b * MINV_ELEMS and B + b * strideB (m rows each)

@@ -24,6 +24,7 @@ struct mi_gp_handle {
   hipEvent_t wait_ev;               // recorded on the main stream behind the (a2) update of tile columns wait_col + 1 ..:
   int wait_col;                     // the panel stream waits for it after the leaf + strip of tile column wait_col
   // tuning options (mi_gp_set_option), all per handle
+  int tail_small;   // option 9: 128x128-tile launches finish their last partial round on 64x64 tiles (default 1)
   int chain_prio;   // s_setprio(3) in the GEMM launches of the panel stream (option 16; the leaf and strip kernels always raise it)
   int lookahead;    // 0 never, 1 by size (default: from LOOKAHEAD_MIN_TILES tile columns on), 2 always
   int lowocc_thr;   // trailing sizes (tile columns) at or below which bulk updates run one workgroup per CU
@@ -133,6 +134,7 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   }
   h->ev_next = 0;
   h->lookahead = 1;
+  h->tail_small = 1;
   h->chain_prio = 1;  // N = 8192: 6.06 -> 5.94 ms, N = 16384: 28.11 -> 27.74 ms (interleaved A/B)
   h->small_below = GemmParams().small_below;
   h->band_rows = GemmParams().band;
@@ -196,6 +198,7 @@ extern "C" int mi_gp_set_option(mi_gp_handle* h, int what, int value) {
   else if (what == 8) h->lowocc_thr = value;
   else if (what == 14) h->band_rows = value;
   else if (what == 16) h->chain_prio = value;
+  else if (what == 9) h->tail_small = value ? 1 : 0;
   else {
     snprintf(h->err, sizeof(h->err), "mi_gp_set_option: unknown option %d", what);
     return -1;
@@ -213,22 +216,29 @@ extern "C" int mi_gp_set_profiling(mi_gp_handle* h, int level) {
 static hipError_t prof_gemm(mi_gp_handle* h, const GemmParams& p, int ak, int bk, int batch, double flops,
                             hipStream_t st) {
   if (h->prof_level >= 2) {
-    if (h->gemm_ev_used + 2 > h->gemm_ev.size()) {
-      for (int i = 0; i < 64; ++i) {
-        hipEvent_t e;
-        hipError_t r = hipEventCreate(&e);
-        if (r != hipSuccess) return r;
-        h->gemm_ev.push_back(e);
+    // one event pair per kernel launch: a split product (gemm_tail_tiles) is two launches, its flops divided by tiles
+    const int tail = gemm_tail_tiles(p, batch);
+    const int tiles = p.tri ? p.nt * (p.nt + 1) / 2 + (p.mt - p.nt) * p.nt : p.mt * p.nt;
+    hipError_t r = hipSuccess;
+    for (int part = 1; part <= (tail > 0 ? 2 : 1) && r == hipSuccess; ++part) {
+      if (h->gemm_ev_used + 2 > h->gemm_ev.size()) {
+        for (int i = 0; i < 64; ++i) {
+          hipEvent_t e;
+          r = hipEventCreate(&e);
+          if (r != hipSuccess) return r;
+          h->gemm_ev.push_back(e);
+        }
       }
+      (void)hipEventRecord(h->gemm_ev[h->gemm_ev_used], st);
+      r = launch_gemm_f64(p, ak, bk, batch, st, part);
+      (void)hipEventRecord(h->gemm_ev[h->gemm_ev_used + 1], st);
+      const size_t pair = h->gemm_ev_used / 2;
+      if (h->gemm_ev_big.size() <= pair) { h->gemm_ev_big.resize(pair + 64); h->gemm_ev_flops.resize(pair + 64); }
+      const double share = tail > 0 ? (part == 1 ? (double)(tiles - tail) : (double)tail) / (double)tiles : 1.0;
+      h->gemm_ev_big[pair] = (part == 1 && !gemm_uses_small_tiles(p, batch)) ? 1 : 0;
+      h->gemm_ev_flops[pair] = flops * share;
+      h->gemm_ev_used += 2;
     }
-    (void)hipEventRecord(h->gemm_ev[h->gemm_ev_used], st);
-    hipError_t r = launch_gemm_f64(p, ak, bk, batch, st);
-    (void)hipEventRecord(h->gemm_ev[h->gemm_ev_used + 1], st);
-    const size_t pair = h->gemm_ev_used / 2;
-    if (h->gemm_ev_big.size() <= pair) { h->gemm_ev_big.resize(pair + 64); h->gemm_ev_flops.resize(pair + 64); }
-    h->gemm_ev_big[pair] = gemm_uses_small_tiles(p, batch) ? 0 : 1;
-    h->gemm_ev_flops[pair] = flops;
-    h->gemm_ev_used += 2;
     h->gemm_flops_acc += flops;
     return r;
   }
@@ -242,6 +252,7 @@ static hipError_t syrk_trapezoid(mi_gp_handle* h, double* A, long lda, int ntr, 
   p.one_per_cu = one_per_cu;
   p.hiprio = (st == h->pstream && h->chain_prio) ? 1 : 0;
   p.small_below = h->small_below;
+  p.tail_small = h->tail_small;
   p.band = h->band_rows;
   p.A = A + (long)r0 * 128 * lda + (long)k0 * 128;
   p.B = p.A;
@@ -513,7 +524,7 @@ static hipError_t gemm_call(mi_gp_handle* h, int ak, int bk, const double* A, lo
   p.A = A; p.B = B; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.strideA = sA; p.strideB = sB; p.strideC = sC;
   p.mt = mt; p.nt = nt; p.k = k; p.tri = tri; p.kmode = kmode; p.alpha = alpha; p.beta = beta;
-  p.small_below = h->small_below; p.band = h->band_rows;
+  p.small_below = h->small_below; p.band = h->band_rows; p.tail_small = h->tail_small;
   return launch_gemm_f64(p, ak, bk, batch, h->stream);
 }
 
@@ -703,7 +714,7 @@ extern "C" int mi_gp_predict_u(mi_gp_handle* h, const double* Xnew_dev, int m, d
   p.lda = ldw; p.ldb = ld; p.ldc = ldw;
   p.strideA = p.strideB = p.strideC = 0;
   p.mt = mp / 128; p.nt = h->ntc; p.k = h->np; p.tri = 0; p.kmode = 4; p.alpha = 1.0; p.beta = 0.0;
-  p.small_below = h->small_below; p.band = h->band_rows;
+  p.small_below = h->small_below; p.band = h->band_rows; p.tail_small = h->tail_small;
   HCK(launch_gemm_f64(p, 0, 1, 1, h->stream), "K* U");
   const int nk = h->spec.nkern, d = h->spec.d;
   const double* th = h->theta_host;

@@ -34,9 +34,9 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 constexpr int TILE = 128;
 constexpr int LDS_LD = 144;
 
-__device__ __forceinline__ void tile_from_index(const GemmParams& p, int idx, int& ti, int& tj) {
-  if (p.tri) {
-    const int ntri = p.nt * (p.nt + 1) / 2;
+__device__ __forceinline__ void tile_from_index(int tri, int nt, int idx, int& ti, int& tj) {
+  if (tri) {
+    const int ntri = nt * (nt + 1) / 2;
     if (idx < ntri) {
       int t = (int)((sqrt(8.0 * (double)idx + 1.0) - 1.0) * 0.5);
       while ((t + 1) * (t + 2) / 2 <= idx) ++t;
@@ -45,39 +45,46 @@ __device__ __forceinline__ void tile_from_index(const GemmParams& p, int idx, in
       tj = idx - t * (t + 1) / 2;
     } else {
       const int rem = idx - ntri;
-      ti = p.nt + rem / p.nt;
-      tj = rem % p.nt;
+      ti = nt + rem / nt;
+      tj = rem % nt;
     }
   } else {
-    ti = idx / p.nt;
-    tj = idx % p.nt;
+    ti = idx / nt;
+    tj = idx % nt;
   }
+}
+__device__ __forceinline__ void tile_from_index(const GemmParams& p, int idx, int& ti, int& tj) {
+  tile_from_index(p.tri, p.nt, idx, ti, tj);
 }
 
 // Band-column-major enumeration of the lower trapezoid (tri) or the full rectangle: bands of R tile rows; inside a band the columns left to right,
 // inside a column the band's rows top to bottom.  The 64 tiles an XCD works on at a time then cover ~R row strips and
 // ~64/R column strips (each fetched into that L2 once and hit by the others) instead of one row strip and 64 column strips.
-__device__ __forceinline__ void tile_from_index_banded(const GemmParams& p, int idx, int R, int& ti, int& tj) {
+__device__ __forceinline__ void tile_from_index_banded(int tri, int mt, int nt, int idx, int R, int& ti, int& tj) {
   auto before = [&](int r) {  // tiles in tile rows [0, r)
-    if (!p.tri) return r * p.nt;
-    return r <= p.nt ? r * (r + 1) / 2 : p.nt * (p.nt + 1) / 2 + (r - p.nt) * p.nt;
+    if (!tri) return r * nt;
+    return r <= nt ? r * (r + 1) / 2 : nt * (nt + 1) / 2 + (r - nt) * nt;
   };
-  int lo = 0, hi = (p.mt + R - 1) / R - 1;
+  int lo = 0, hi = (mt + R - 1) / R - 1;
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
     if (before(mid * R) <= idx) lo = mid; else hi = mid - 1;
   }
-  const int r0 = lo * R, r1 = min(r0 + R, p.mt), h = r1 - r0;
+  const int r0 = lo * R, r1 = min(r0 + R, mt), h = r1 - r0;
   int e = idx - before(r0);
-  const int cfull = p.tri ? min(r0 + 1, p.nt) : p.nt;  // columns that hold all h rows of the band
+  const int cfull = tri ? min(r0 + 1, nt) : nt;  // columns that hold all h rows of the band
   if (e < cfull * h) { tj = e / h; ti = r0 + e % h; return; }
   e -= cfull * h;
-  for (tj = cfull; tj < p.nt; ++tj) {    // the band's own triangle: column tj holds rows tj .. r1-1
+  for (tj = cfull; tj < nt; ++tj) {    // the band's own triangle: column tj holds rows tj .. r1-1
     const int cnt = r1 - tj;
     if (e < cnt) { ti = tj + e; return; }
     e -= cnt;
   }
-  ti = r1 - 1; tj = min(ti, p.nt - 1);
+  ti = r1 - 1; tj = min(ti, nt - 1);
+}
+
+__device__ __forceinline__ void tile_from_index_banded(const GemmParams& p, int idx, int R, int& ti, int& tj) {
+  tile_from_index_banded(p.tri, p.mt, p.nt, idx, R, ti, tj);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -364,7 +371,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel_s(GemmParams p) {
   const int wr = wave >> 1, wc = wave & 1;
 
   int ti, tj;
-  tile_from_index(p, blockIdx.x, ti, tj);
+  if (p.sub_base >= 0) {
+    // tail of a 128x128-tile launch: this workgroup is one quadrant of parent tile sub_base + blockIdx.x / 4
+    int pti, ptj;
+    const int pidx = p.sub_base + ((int)blockIdx.x >> 2), quad = (int)blockIdx.x & 3;
+    if (p.band > 0 && p.tri) tile_from_index_banded(p.tri, p.sub_mt, p.sub_nt, pidx, p.band, pti, ptj);
+    else tile_from_index(p.tri, p.sub_nt, pidx, pti, ptj);
+    ti = 2 * pti + (quad >> 1);
+    tj = 2 * ptj + (quad & 1);
+    if (p.tri && tj > ti) return;  // the quadrant above the diagonal of a diagonal parent tile
+  } else {
+    tile_from_index(p, blockIdx.x, ti, tj);
+  }
   if (p.kmode == 2) ti = p.mt - 1 - ti;
   if (p.kmode == 4 && !p.tri) { tj = p.nt - 1 - (int)blockIdx.x / p.mt; ti = (int)blockIdx.x % p.mt; }  // longest-k columns first (LPT order)
   const int i0 = ti * TS, j0 = tj * TS;
@@ -534,15 +552,37 @@ static int tile_count(const GemmParams& p) {
 // launches with fewer 128x128 tiles than p.small_below run on 64x64 tiles (4x the workgroups, 1/4 of the latency)
 bool gemm_uses_small_tiles(const GemmParams& p, int batch) { return tile_count(p) * batch < p.small_below && p.kmode != 2; }
 
-hipError_t launch_gemm_f64(const GemmParams& p, int opA_kmajor, int opB_kmajor, int batch, hipStream_t stream) {
+// The 128x128-tile kernel runs its tiles in rounds of 512 (two workgroups on each of 256 CUs, 218 us per round at
+// k = 1024): a last round with few tiles costs a whole round (7 % of the nine bulk launches of an N = 16384
+// factorisation).  Uniform-k launches therefore hand the tiles beyond the last full round to the 64x64-tile kernel (a
+// quarter of the time per round): worth it up to 384 such tiles (three quarter-rounds).  The rule does not look at
+// one_per_cu or the stream, so results stay bit-identical across the scheduling options.
+constexpr int ROUND_TILES = 512, TAIL_MAX_TILES = 384;
+int gemm_tail_tiles(const GemmParams& p, int batch) {
+  if (!p.tail_small || p.kmode != 0 || batch != 1 || gemm_uses_small_tiles(p, batch)) return 0;
+  const int nblk = tile_count(p), rem = nblk % ROUND_TILES;
+  return (nblk > ROUND_TILES && rem > 0 && rem <= TAIL_MAX_TILES) ? rem : 0;
+}
+
+hipError_t launch_gemm_f64(const GemmParams& p, int opA_kmajor, int opB_kmajor, int batch, hipStream_t stream, int part) {
   const int nblk = tile_count(p);
   if (nblk <= 0 || batch <= 0) return hipSuccess;
-  if (gemm_uses_small_tiles(p, batch)) {
-    // few 128x128 tiles: cut them into 64x64 ones (same enumeration, tile units halve)
+  const bool small = gemm_uses_small_tiles(p, batch);
+  const int tail = gemm_tail_tiles(p, batch);
+  // 64x64 tiles: the whole product (few 128x128 tiles: same enumeration, tile units halve) or the `ntail` last tiles of
+  // a 128x128-tile launch
+  auto launch_small = [&](int ntail) -> hipError_t {
     GemmParams q = p;
     q.mt = 2 * p.mt;
     q.nt = 2 * p.nt;
-    dim3 grid(tile_count(q), 1, batch), block(256);
+    int nwg = tile_count(q);
+    if (ntail > 0) {
+      q.sub_base = nblk - ntail;
+      q.sub_mt = p.mt;
+      q.sub_nt = p.nt;
+      nwg = 4 * ntail;
+    }
+    dim3 grid(nwg, 1, batch), block(256);
     // one_per_cu: unused dynamic LDS on top of the 60 KB static image pushes the request over half a CU
     const size_t pad = p.one_per_cu ? LDS_ONE_PER_CU - sizeof(double) * 2 * vs::NBUF * vs::OPER_S : 0;
     if (!opA_kmajor && !opB_kmajor) gemm_f64_kernel_s<false, false><<<grid, block, pad, stream>>>(q);
@@ -550,14 +590,19 @@ hipError_t launch_gemm_f64(const GemmParams& p, int opA_kmajor, int opB_kmajor, 
     else if (opA_kmajor && opB_kmajor) gemm_f64_kernel_s<true, true><<<grid, block, pad, stream>>>(q);
     else gemm_f64_kernel_s<true, false><<<grid, block, pad, stream>>>(q);
     return hipGetLastError();
+  };
+  if (small) return part == 2 ? hipSuccess : launch_small(0);
+  if (part != 2) {
+    dim3 grid(nblk - tail, 1, batch), block(vb::NT_B);
+    const size_t lds = p.one_per_cu ? LDS_ONE_PER_CU : sizeof(double) * 4 * vb::OPER_B;
+    if (!opA_kmajor && !opB_kmajor) gemm_f64_kernel_b<false, false><<<grid, block, lds, stream>>>(p);
+    else if (!opA_kmajor && opB_kmajor) gemm_f64_kernel_b<false, true><<<grid, block, lds, stream>>>(p);
+    else if (opA_kmajor && opB_kmajor) gemm_f64_kernel_b<true, true><<<grid, block, lds, stream>>>(p);
+    else gemm_f64_kernel_b<true, false><<<grid, block, lds, stream>>>(p);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
   }
-  dim3 grid(nblk, 1, batch), block(vb::NT_B);
-  const size_t lds = p.one_per_cu ? LDS_ONE_PER_CU : sizeof(double) * 4 * vb::OPER_B;
-  if (!opA_kmajor && !opB_kmajor) gemm_f64_kernel_b<false, false><<<grid, block, lds, stream>>>(p);
-  else if (!opA_kmajor && opB_kmajor) gemm_f64_kernel_b<false, true><<<grid, block, lds, stream>>>(p);
-  else if (opA_kmajor && opB_kmajor) gemm_f64_kernel_b<true, true><<<grid, block, lds, stream>>>(p);
-  else gemm_f64_kernel_b<true, false><<<grid, block, lds, stream>>>(p);
-  return hipGetLastError();
+  return (tail > 0 && part != 1) ? launch_small(tail) : hipSuccess;
 }
 
 hipError_t gemm_f64_enable_lds() {

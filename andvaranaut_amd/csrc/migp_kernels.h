@@ -23,10 +23,17 @@ struct GemmParams {
   int hiprio = 0;                   // 64x64-tile kernel only: raise the waves' issue priority (launches on the panel chain)
   int one_per_cu = 0;               // request > half a CU's LDS so that one workgroup per CU runs (leaves room for
                                     // the panel chain's leaf / strip kernels next to a bulk update)
+  int tail_small = 1;               // uniform-k 128x128-tile launches: the tiles beyond the last full round of 512 go to the
+                                    // 64x64-tile kernel in a second launch (mi_gp_set_option 9)
+  // set by the launcher for that second launch: 64x64 tile 4 e + quadrant belongs to 128x128 tile sub_base + e of the
+  // parent enumeration (sub_mt x sub_nt tiles of 128); -1: off
+  int sub_base = -1, sub_mt = 0, sub_nt = 0;
 };
 // opX_kmajor = 0: operand stored [x][k] (A row-major m x k / B stored n x k, i.e. "B^T");
 // opX_kmajor = 1: operand stored [k][x].
-hipError_t launch_gemm_f64(const GemmParams& p, int opA_kmajor, int opB_kmajor, int batch, hipStream_t stream);
+// part: 0 the whole product; 1 / 2 only the first / second launch of a split one (per-launch event timing); see gemm_tail_tiles
+hipError_t launch_gemm_f64(const GemmParams& p, int opA_kmajor, int opB_kmajor, int batch, hipStream_t stream, int part = 0);
+int gemm_tail_tiles(const GemmParams& p, int batch);  // 128x128 tiles that the second launch of a split product takes (0: not split)
 hipError_t gemm_f64_enable_lds();
 bool gemm_uses_small_tiles(const GemmParams& p, int batch);  // true: the 64x64-tile kernel will run
 

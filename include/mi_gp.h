@@ -118,11 +118,13 @@ int mi_gp_predict_grad(mi_gp_handle* h, const double* Xnew_dev, int m, double* w
  *        defaults: never 16, else 8; with look-ahead active, problems of up to 64 tile columns use at most 4
  *   7  GEMM launches with fewer 128x128 tiles than this run on 64x64 tiles (default 1024)
  *   8  trailing size at or below which look-ahead bulk updates run one workgroup per CU (default: always)
+ *   9  128x128-tile GEMM launches with uniform k hand the tiles beyond their last full round of 512 to the 64x64-tile
+ *      kernel (default 1: a last round with few tiles costs a whole round; sharded N=65536 on one rank 1.52 -> 1.47 s)
  *   14 band height (tile rows) of the band-column-major tile order of uniform-k trapezoid launches (default 8, 0 = row-major)
  *   16 panel-stream GEMM launches raise their waves' issue priority (s_setprio 3) against the bulk update's (default 1)
- * 8, 14 and 16 only change scheduling (bit-identical results); 2, 4-7 regroup sums (agreement to rounding), and so does 0 where
+ * 8, 14 and 16 only change scheduling (bit-identical results); 2, 4-7, 9 regroup sums (agreement to rounding), and so does 0 where
  * it changes the super-panel width (36 to 64 tile columns).
- * Unknown ids return -1.  (Round 1's options 1, 3, 9-13 -- GEMM variants, hipGraph replay, persistent bulk kernels,
+ * Unknown ids return -1.  (Round 1's options 1, 3, 10-13 -- GEMM variants, hipGraph replay, persistent bulk kernels,
  * exclusive leaf, fused leaf + strip -- are gone with the code they selected.) */
 int mi_gp_set_option(mi_gp_handle* h, int what, int value);
 

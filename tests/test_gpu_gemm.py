@@ -1,0 +1,51 @@
+"""The fp64 MFMA GEMM behind the C-ABI (mi_gp_gemm_f64: the SYRK / trapezoid updates of the factorisation, gpmcmc.py:313's
+dpotrf internals) against a plain PyTorch fp64 product, on the launch shapes the factorisation issues: the 64x64-tile
+kernel, the 128x128-tile kernel, and a 128x128-tile launch whose last partial round is finished on 64x64 tiles."""
+import ctypes
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(m, n, k, tri, seed):
+    import torch
+
+    from andvaranaut_amd import _lib
+
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(seed)
+    ld = max(m, n) + 16
+    P = torch.randn(m, k + 16, dtype=torch.float64, device=dev, generator=g)[:, :k]  # row-major m x k, ld k + 16
+    Q = P if tri else torch.randn(n, k + 16, dtype=torch.float64, device=dev, generator=g)[:, :k]  # the B operand, n x k
+    C0 = torch.randn(m, ld, dtype=torch.float64, device=dev, generator=g)
+    C = C0.clone()
+    r = lib.mi_gp_gemm_f64(0, 1, m, n, k, -1.0, P.data_ptr(), k + 16, Q.data_ptr(), k + 16, 1.0, C.data_ptr(), ld, tri, 0, 1,
+                           0, 0, 0, None)
+    assert r == 0, lib.mi_gp_last_global_error()
+    torch.cuda.synchronize()
+    ref = C0[:, :n] - P @ Q[:n].T
+    got = C[:, :n]
+    if tri:  # element-wise lower trapezoid is guaranteed; the strict upper part of diagonal blocks is unspecified
+        mask = torch.tril(torch.ones(m, n, dtype=torch.bool, device=dev))
+        err = ((got - ref).abs() * mask).max().item()
+        untouched = torch.triu(torch.ones(m, n, dtype=torch.bool, device=dev), diagonal=128)  # tiles above the block diagonal
+        assert torch.equal(got[untouched], C0[:, :n][untouched])
+    else:
+        err = (got - ref).abs().max().item()
+    assert torch.equal(C[:, n:], C0[:, n:])  # nothing beyond the n columns is written
+    assert err <= 1e-12 * k ** 0.5 * 16, (m, n, k, tri, err)
+
+
+@pytest.mark.parametrize("m,n,k,tri", [
+    (1152, 384, 128, 1),     # 64x64-tile kernel, short k (in-panel update)
+    (2048, 2048, 512, 1),    # 64x64-tile kernel, 136 tiles of 128^2
+    (6016, 6016, 256, 1),    # 1128 tiles: 128x128 kernel, 1024 + a tail of 104 tiles finished on 64x64 tiles
+    (5888, 5888, 128, 1),    # 1081 tiles: tail of 57, among them diagonal tiles (upper quadrant skipped)
+    (4096, 4224, 128, 0),    # full rectangle, 1056 tiles: tail of 32
+    (8192, 1024, 1024, 1),   # trapezoid with rows below the triangle, 476 tiles (64x64 kernel)
+    (9216, 2048, 256, 1),    # trapezoid, 1032 tiles: tail of 8
+])
+def test_gemm_matches_torch_fp64(m, n, k, tri):
+    _run(m, n, k, tri, seed=m + n + k)

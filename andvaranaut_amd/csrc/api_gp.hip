@@ -35,7 +35,6 @@ struct mi_gp_handle {
   bool have_data;
   // handle-owned small scratch
   double* theta_dev;    // [ntheta]
-  double* out_dev;      // [16] scalars
   double* dinv_dev;     // [ntc][128][128] explicit inverses of the diagonal blocks of L (leaf output, strip operand)
   double* alpha_dev;    // [np] K^-1 y
   double* part_dev;     // [grad_contract_blocks(n)][ntheta]
@@ -80,7 +79,7 @@ static void release_handle(mi_gp_handle* h) {
   (void)hipSetDevice(h->device);
   if (h->pstream) (void)hipStreamSynchronize(h->pstream);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  (void)hipFree(h->theta_dev); (void)hipFree(h->out_dev); (void)hipFree(h->dinv_dev); (void)hipFree(h->info_dev);
+  (void)hipFree(h->theta_dev); (void)hipFree(h->dinv_dev); (void)hipFree(h->info_dev);
   (void)hipFree(h->alpha_dev); (void)hipFree(h->part_dev); (void)hipFree(h->gxs_dev); (void)hipFree(h->grad_dev);
   if (h->grad_host) (void)hipHostFree(h->grad_host);
   if (h->out_host) (void)hipHostFree(h->out_host);
@@ -144,7 +143,6 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   h->lowocc_thr = 1 << 20;
   h->w_thr[0] = 1 << 20; h->w_thr[1] = 0; h->w_thr[2] = 0;
   if (e == hipSuccess) e = hipMalloc(&h->theta_dev, sizeof(double) * h->ntheta);
-  if (e == hipSuccess) e = hipMalloc(&h->out_dev, sizeof(double) * 16);
   if (e == hipSuccess) e = hipMalloc(&h->dinv_dev, sizeof(double) * MINV_ELEMS * (size_t)h->ntc);
   if (e == hipSuccess) e = hipMalloc(&h->alpha_dev, sizeof(double) * h->np);
   if (e == hipSuccess) e = hipMalloc(&h->part_dev, sizeof(double) * (size_t)grad_contract_blocks(h->n) * h->ntheta);

@@ -34,9 +34,14 @@ DINV_ROWS = 128  # pwt * MINV leaf-inverse doubles appended to a broadcast panel
 
 
 def panel_tiles(ntc, world):
-    """Super-panel width in 128-column tiles: 1024 columns (k = 1024 updates, half as many and twice as large
-    broadcasts: one rank, N = 16384: LML 42.7 -> 36.0 ms, LML + gradient 101 -> 91 ms) once every rank still owns
-    at least four panels, else 512."""
+    """Super-panel width in 128-column tiles.  One or two ranks: 1024 columns (k = 1024 updates, half as many and twice
+    as large broadcasts; one rank, N = 16384: LML 42.7 -> 36.0 ms, LML + gradient 101 -> 91 ms) once every rank still owns
+    at least four panels, else 512.  Four ranks and more: 512 -- not measured (no multi-GPU box yet), a model: with the
+    bulk updates split over the ranks the serial chain `owner updates the next panel -> factors it -> broadcasts it`
+    becomes the critical path, and its update + factor work per column grows with the panel width (N = 65536 on 8 ranks:
+    ~5.7 ms per 1024-column panel x 64 against ~2 ms per 512-column panel x 128, for ~0.17 s of bulk updates per rank)."""
+    if world >= 4:
+        return 4
     return 8 if ntc >= 32 * world else 4
 
 

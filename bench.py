@@ -173,7 +173,7 @@ def sharded_record(args, rank, world, dev, N, d, kernel, steps, warmup, grad=Fal
     from andvaranaut_amd.distributed import DistGP
 
     X, y = synth_problem(N, d, seed=0)
-    gp = DistGP(X, y, kernel, device=dev.index)
+    gp = DistGP(X, y, kernel, device=dev.index, panel_width_tiles=args.sharded_panel_tiles or None)
     thetas = theta_sequence(d, warmup + steps, seed=0)
     for i in range(len(thetas)):  # config 4 is RBF at d=32: keep cond(K) in the benchmark regime
         thetas[i][-2] = 1e-4
@@ -232,6 +232,8 @@ def main():
     ap.add_argument("--sharded-kernel", default="RBF")
     ap.add_argument("--sharded-steps", type=int, default=2)
     ap.add_argument("--sharded-timeout", type=float, default=420.0)
+    ap.add_argument("--sharded-panel-tiles", type=int, default=0,
+                    help="sharded driver's panel width in 128-column tiles (0: its own rule: 8 up to two ranks, else 4)")
     ap.add_argument("--grad", action="store_true", help="with --sharded: time LML + gradient (sharded K^-1) instead of the LML")
     ap.add_argument("--grad-steps", type=int, default=5, help="LML + gradient evaluations timed after the LML region (0: skip)")
     ap.add_argument("--no-lookahead", action="store_true", help="disable the look-ahead stream everywhere (profiling aid)")

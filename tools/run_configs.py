@@ -38,4 +38,21 @@ out["config5_nuts"] = {"N": N, "d": d, "draws": 30, "tune": 30, "leapfrogs": r["
                        "grad_evals_per_s": r["n_leapfrog"] / dt, "mean_tree_depth": r["mean_tree_depth"], "diverging": r["diverging"],
                        "lp_mean": float(np.mean(r["lp"]))}
 print(json.dumps(out["config5_nuts"]), flush=True)
+# the same with three chains side by side on this GPU (what GPMCMC.fit(method='mcmc_*') does with more chains than GPUs)
+import threading
+others = [MiGP(X, y, "RBF") for _ in range(2)]
+handles = [gp] + others
+res = [None] * 3
+def chain(i):
+    h = handles[i]
+    res[i] = sample_chain(lambda q: model.logp_dlogp(q, h.lml_grad), qmap, draws=30, tune=30, seed=i)
+ths = [threading.Thread(target=chain, args=(i,)) for i in range(3)]
+t0 = time.perf_counter()
+for t in ths: t.start()
+for t in ths: t.join()
+dt3 = time.perf_counter() - t0
+nl = sum(r_["n_leapfrog"] for r_ in res)
+out["config5_nuts_three_chains_one_gpu"] = {"chains": 3, "leapfrogs": nl, "seconds": dt3, "grad_evals_per_s": nl / dt3,
+                                             "diverging": [r_["diverging"] for r_ in res]}
+print(json.dumps(out["config5_nuts_three_chains_one_gpu"]), flush=True)
 json.dump(out, open("gpurun_out/configs_3_5.json", "w"), indent=1)

@@ -220,8 +220,21 @@ __global__ __launch_bounds__(vb::NT_B, 2) void gemm_f64_kernel_b(GemmParams p) {
   //   k4-step 3: the 8 ds_write2 of chunk c+1
   // A burst of LDS / VMEM issue in both co-resident workgroups at once left the MFMA pipe 88 % busy; spread out
   // it is 93 % (8192^3: 70.3 -> 73.3 TFLOP/s, rocBLAS 72.9).
-  auto chunk_body = [&](int c, auto S) {
+  // C read-modify-write: the first two of its four row groups are requested during the LAST two chunks of the k loop (in
+  // place of those chunks' global prefetches, which would be redundant reloads), so that their round trip hides under
+  // 128 MFMAs instead of following the loop
+  const double alpha = p.alpha, beta = p.beta;
+  double* cbase = C + (long)(i0 + wr * 64 + kq) * p.ldc + j0 + wc * 64 + l15;
+  double4_t cv[2][4];
+  auto load_group = [&](int set, int a) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cv[set][b][r] = cbase[(long)(16 * a + 4 * r) * p.ldc + 16 * b];
+  };
+  auto chunk_body = [&](int c, auto S, auto LASTC) {
     constexpr int s = decltype(S)::value;
+    constexpr int lastc = decltype(LASTC)::value;  // 0: inside the loop; 1 / 2: second-to-last / last chunk
     constexpr int boff = s * OPER_B;
     const bool adv = (c + 2 < nchunk);
     Ag += adv ? stepA : 0;
@@ -231,8 +244,12 @@ __global__ __launch_bounds__(vb::NT_B, 2) void gemm_f64_kernel_b(GemmParams p) {
       const int cur = kk & 1;
       __builtin_amdgcn_sched_barrier(0);
       if (kk == 0) {
-        vb::chunk_load(Ag, gA, sA, ra[s]);
-        vb::chunk_load(Bg, gB, sB, rb[s]);
+        if (lastc == 0) {
+          vb::chunk_load(Ag, gA, sA, ra[s]);
+          vb::chunk_load(Bg, gB, sB, rb[s]);
+        } else {
+          load_group(lastc - 1, lastc - 1);
+        }
       }
       if (kk + 1 < BKB / 4) load_frags(cur ^ 1, boff, kk + 1);
 #pragma unroll
@@ -276,31 +293,24 @@ __global__ __launch_bounds__(vb::NT_B, 2) void gemm_f64_kernel_b(GemmParams p) {
     __syncthreads();
     load_frags(0, boff ^ OPER_B, 0);
   };
-  for (int c = 0; c < nchunk; c += 2) {  // k is a multiple of 128, so nchunk is even
-    chunk_body(c, std::integral_constant<int, 0>());
-    chunk_body(c + 1, std::integral_constant<int, 1>());
+  int c = 0;
+  for (; c + 2 < nchunk; c += 2) {  // k is a multiple of 128, so nchunk is even and >= 8
+    chunk_body(c, std::integral_constant<int, 0>(), std::integral_constant<int, 0>());
+    chunk_body(c + 1, std::integral_constant<int, 1>(), std::integral_constant<int, 0>());
   }
+  chunk_body(c, std::integral_constant<int, 0>(), std::integral_constant<int, 1>());
+  chunk_body(c + 1, std::integral_constant<int, 1>(), std::integral_constant<int, 2>());
 
-  const double alpha = p.alpha, beta = p.beta;
-  double* cbase = C + (long)(i0 + wr * 64 + kq) * p.ldc + j0 + wc * 64 + l15;
   if (beta != 0.0) {
-    // read-modify-write in four row groups, the next group's loads in flight while this one is stored
-    double4_t cv[2][4];
-    auto load_group = [&](int set, int a) {
-#pragma unroll
-      for (int b = 0; b < 4; ++b)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) cv[set][b][r] = cbase[(long)(16 * a + 4 * r) * p.ldc + 16 * b];
-    };
-    load_group(0, 0);
+    // row groups 0 and 1 are in registers; groups 2 and 3 are requested while 0 and 1 are stored
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-      if (a + 1 < 4) load_group((a + 1) & 1, a + 1);
 #pragma unroll
       for (int b = 0; b < 4; ++b)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           cbase[(long)(16 * a + 4 * r) * p.ldc + 16 * b] = alpha * acc[a][b][r] + beta * cv[a & 1][b][r];
+      if (a + 2 < 4) load_group(a & 1, a + 2);
     }
   } else {
 #pragma unroll

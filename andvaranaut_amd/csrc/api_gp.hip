@@ -39,7 +39,6 @@ struct mi_gp_handle {
   double* alpha_dev;    // [np] K^-1 y
   double* part_dev;     // [grad_contract_blocks(n)][ntheta]
   double* gxs_dev;      // [grad_x_splits][n][d] partial dLML/dX (allocated on first mi_gp_grad_x)
-  double* grad_dev;     // [ntheta]
   double* grad_host;    // pinned [ntheta]
   int* info_dev;
   double* out_host;     // pinned [16]
@@ -80,7 +79,7 @@ static void release_handle(mi_gp_handle* h) {
   if (h->pstream) (void)hipStreamSynchronize(h->pstream);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   (void)hipFree(h->theta_dev); (void)hipFree(h->dinv_dev); (void)hipFree(h->info_dev);
-  (void)hipFree(h->alpha_dev); (void)hipFree(h->part_dev); (void)hipFree(h->gxs_dev); (void)hipFree(h->grad_dev);
+  (void)hipFree(h->alpha_dev); (void)hipFree(h->part_dev); (void)hipFree(h->gxs_dev);
   if (h->grad_host) (void)hipHostFree(h->grad_host);
   if (h->out_host) (void)hipHostFree(h->out_host);
   if (h->theta_host) (void)hipHostFree(h->theta_host);
@@ -146,7 +145,6 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   if (e == hipSuccess) e = hipMalloc(&h->dinv_dev, sizeof(double) * MINV_ELEMS * (size_t)h->ntc);
   if (e == hipSuccess) e = hipMalloc(&h->alpha_dev, sizeof(double) * h->np);
   if (e == hipSuccess) e = hipMalloc(&h->part_dev, sizeof(double) * (size_t)grad_contract_blocks(h->n) * h->ntheta);
-  if (e == hipSuccess) e = hipMalloc(&h->grad_dev, sizeof(double) * h->ntheta);
   if (e == hipSuccess) e = hipHostMalloc(&h->grad_host, sizeof(double) * h->ntheta);
   if (e == hipSuccess) e = hipMalloc(&h->info_dev, sizeof(int) * 4);
   if (e == hipSuccess) e = hipHostMalloc(&h->out_host, sizeof(double) * 16);
@@ -416,12 +414,6 @@ static int enqueue_factor(mi_gp_handle* h, int noise_form, bool prof) {
 static int enqueue_gradient(mi_gp_handle* h, bool prof);
 static hipError_t inverse_transpose(mi_gp_handle* h);
 
-static int download_results(mi_gp_handle* h, int what) {
-  if (what == 2)
-    HCK(hipMemcpyAsync(h->grad_host, h->grad_dev, sizeof(double) * h->ntheta, hipMemcpyDeviceToHost, h->stream), "grad download");
-  return 0;
-}
-
 static int enqueue_all(mi_gp_handle* h, int what, bool prof) {
   if (int r = enqueue_factor(h, what == 1 ? 1 : 0, prof)) return r;
   if (what == 2) return enqueue_gradient(h, prof);
@@ -438,8 +430,9 @@ static int run_evaluation(mi_gp_handle* h, int what) {
   const bool prof = h->prof_level >= 1;
   h->gemm_ev_used = 0;
   h->gemm_flops_acc = 0.0;
-  if (int r = enqueue_all(h, what, prof)) return r;  // theta travels inside the first kernel (set_yrows_kernel)
-  return download_results(h, what);
+  // theta travels inside the first kernel (set_yrows_kernel); the scalars and the gradient are written to pinned host
+  // memory by the kernels that produce them: no copy launches
+  return enqueue_all(h, what, prof);
 }
 
 static int factor_internal(mi_gp_handle* h, const double* theta, int what) {
@@ -574,8 +567,9 @@ static int enqueue_gradient(mi_gp_handle* h, bool prof) {
                 0.0, 1), "lauum");
   if (prof) (void)hipEventRecord(h->ev[6], h->stream);
   HCK(launch_trmv_upper(h->buf.Z_dev, ld, h->buf.K_dev + (long)h->np * ld, h->n, h->alpha_dev, h->stream), "trmv");
+  // the final reduction writes the gradient straight into the handle's pinned host buffer (device-visible)
   HCK(launch_grad_contract(h->spec, h->theta_dev, h->buf.X_dev, h->n, h->buf.W_dev, ld, h->alpha_dev, h->part_dev,
-                           h->grad_dev, h->stream), "grad_contract");
+                           h->grad_host, h->stream), "grad_contract");
   if (prof) (void)hipEventRecord(h->ev[7], h->stream);
   return 0;
 }

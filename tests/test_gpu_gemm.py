@@ -44,7 +44,10 @@ def _run(m, n, k, tri, seed):
     (6016, 6016, 256, 1),    # 1128 tiles: 128x128 kernel, 1024 + a tail of 104 tiles finished on 64x64 tiles
     (5888, 5888, 128, 1),    # 1081 tiles: tail of 57, among them diagonal tiles (upper quadrant skipped)
     (4096, 4224, 128, 0),    # full rectangle, 1056 tiles: tail of 32
-    (8192, 1024, 1024, 1),   # trapezoid with rows below the triangle, 476 tiles (64x64 kernel)
+    (8192, 1024, 1024, 1),   # trapezoid with rows below the triangle, 476 tiles (64x64 kernel, several rounds)
+    (4096, 4096, 512, 1),    # 528 tiles, triangle only
+    (6144, 768, 256, 1),     # 273 tiles, short k
+    (4096, 3072, 256, 0),    # rectangle, 768 tiles
     (9216, 2048, 256, 1),    # trapezoid, 1032 tiles: tail of 8
 ])
 def test_gemm_matches_torch_fp64(m, n, k, tri):

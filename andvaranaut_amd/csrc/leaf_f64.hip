@@ -97,6 +97,10 @@ __device__ __forceinline__ double bcast_lane(double v, int src) {
 // DPP row_newbcast control (the only DPP form fp64 VALU ops have on gfx90a+).  hipcc cannot see the
 // "VALU write -> DPP read of the same VGPR" hazard (2 wait states) inside inline asm: callers must
 // not pass a `src` written by the immediately preceding VALU instruction (mov_rowbcast pads itself).
+// Two wait states tied to the VALUE: the asm takes `v` in and out, so its producer is scheduled before the s_nop and every
+// DPP consumer after it (a bare `asm volatile("s_nop 1")` orders nothing -- the compiler moved rs's last Newton step behind
+// it in round 2's build; tests/test_dpp_hazard.py disassembles the library and checks every DPP read).
+__device__ __forceinline__ void dpp_settle(double& v) { asm volatile("s_nop 1" : "+v"(v)); }
 template <int C>
 __device__ __forceinline__ void fmac_rowbcast(double& acc, double src, double mul) {
   asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
@@ -324,9 +328,9 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
     ElimStep<0>::run(a, mov_rowbcast<0>(a[0]), bad);
     if (bad != 0 && lane == 0) atomicMin(info, col0 + j0 + bad);
     // normalise: L[r][c] = a[c] * rsqrt(p_c); lane c holds p_c = a[c]
-    const double rs = fast_rsqrt(a[r]);
+    double rs = fast_rsqrt(a[r]);
     double l[SB];
-    asm volatile("s_nop 1" ::: "memory");  // rs was written by VALU just now: two wait states before the DPP reads below
+    dpp_settle(rs);  // rs was written by VALU just now: two wait states before the DPP reads below
     ScaleCols<0>::run(a, rs, l);
     double* row = S + soff(j0 + r) + j0;
     double* LdT = LdT2 + (jb & 1) * SB * SB;

@@ -486,9 +486,12 @@ class GPMCMC(ConsumersMixin):
             if chains_per_device is not None:
                 return max(1, min(int(chains_per_device), nchain))
             npad = (len(yin) + 127) // 128 * 128
-            need = 3 * (npad + 128) * (npad + 16) * 8  # K, U = L^-T and K^-1 of one gradient-capable handle
+            # one gradient-capable handle: K, U = L^-T and K^-1; the leaf inverses (128 x 128 per tile column); X, the
+            # data-side gradient partials (up to 8 column splits of n x d) and the small vectors
+            need = (3 * (npad + 128) * (npad + 16) + (npad // 128) * 128 * 128 + 10 * npad * xin.shape[1] + 8 * npad) * 8
             free, _total = torch.cuda.mem_get_info(dev)
-            return max(1, min(3, nchain, 1 + int(0.8 * free // need)))  # the first lane's handle exists already on self.device
+            base = 1 if dev == self.device else 0  # the first lane's handle exists already -- on self.device only
+            return max(1, min(3, nchain, base + int(0.8 * free // need)))
 
         # a lane = one host thread + one handle; the chains of a device are dealt round-robin to its lanes
         def run_lane(dev, cs, h_existing):

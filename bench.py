@@ -55,6 +55,11 @@ def theta_sequence(d, steps, seed):
     return out
 
 
+def reference_theta(d):
+    """SURVEY.md section 8d grid point (== oracle.synth_theta(d)): the theta of the parity record in cpu_baseline."""
+    return np.concatenate([np.exp(np.linspace(np.log(0.4), np.log(1.5), d)), [1.7], [1.0], [1e-4, 1e-6]])
+
+
 def host_cores():
     """Cores this process may actually use: affinity mask, capped by the cgroup CPU quota."""
     try:
@@ -70,10 +75,11 @@ def host_cores():
     return ncpu
 
 
-def cpu_baseline(N, d, kernel, full=True):
+def cpu_baseline(N, d, kernel, full=True, gpu_lml=None):
     """Oracle (NumPy/SciPy restatement of the reference's PyMC -> SciPy LAPACK path) timed on this box's host
-    cores.  ``full``: ONE LML evaluation at the benchmark's own N (measured, ~1 min of CPU at N=16384); the
-    LML + gradient leg is timed at N/4 and scaled by N^3 (a full one is ~3x the LML: too long for a default run).
+    cores.  ``full``: ONE LML evaluation at the benchmark's own N (measured, ~10 s of CPU at N=16384) whose VALUE is
+    kept and compared with the device's LML on the same X, y, theta (``rel_diff_vs_gpu``: the north star's rtol 1e-10);
+    the LML + gradient leg is timed at min(N, 8192) and scaled by N^3 (a full one at N=16384 is ~150 s).
     BLAS threads = the box's CPU share for one GPU (16), not the machine's core count: OpenBLAS with more threads
     than the cgroup quota allows is several times slower."""
     from oracle import gp_oracle as orc
@@ -91,28 +97,36 @@ def cpu_baseline(N, d, kernel, full=True):
     def one(Ns):
         X, y = orc.synth_problem(Ns, d, seed=0)
         theta = orc.synth_theta(d)
+        assert np.array_equal(theta, reference_theta(d))
         t0 = time.perf_counter()
         K = orc.noisy_cov(X, [kernel], [], theta)
         t1 = time.perf_counter()
         L = sla.cholesky(K, lower=True, overwrite_a=True, check_finite=False)
         t2 = time.perf_counter()
         beta = sla.solve_triangular(L, y, lower=True, check_finite=False)
-        _ = -0.5 * beta @ beta - np.log(np.diag(L)).sum()
+        val = -0.5 * Ns * np.log(2.0 * np.pi) - 0.5 * beta @ beta - np.log(np.diag(L)).sum()
         t3 = time.perf_counter()
-        return t1 - t0, t2 - t1, t3 - t2
+        return t1 - t0, t2 - t1, t3 - t2, float(val)
 
     Ns = N if full else min(N, 4096)
-    t_asm, t_chol, t_solve = one(Ns)
+    t_asm, t_chol, t_solve, cpu_val = one(Ns)
     s = N / Ns
     t_full = t_asm * s ** 2 + t_chol * s ** 3 + t_solve * s ** 2
     # LML + analytic gradient (K^-1 via dpotri-style solves + contraction), bounded sample
-    Ng = min(N, 4096)
+    Ng = min(N, 8192 if full else 4096)
     Xg, yg = orc.synth_problem(Ng, d, seed=0)
     t0 = time.perf_counter()
     orc.lml_grad(Xg, yg, [kernel], [], orc.synth_theta(d))
-    t_grad = (time.perf_counter() - t0) * (N / Ng) ** 3
+    t_grad_meas = time.perf_counter() - t0
+    t_grad = t_grad_meas * (N / Ng) ** 3
     how = "measured at the full size, one evaluation" if Ns == N else f"measured at N={Ns}, extrapolated by N^2/N^3"
+    parity = {}
+    if Ns == N and gpu_lml is not None:
+        # same X, y (synth_problem seed 0) and theta (oracle.synth_theta) as the device evaluation `gpu_lml`
+        parity = {"lml_cpu": cpu_val, "lml_gpu": float(gpu_lml),
+                  "rel_diff_vs_gpu": abs(cpu_val - float(gpu_lml)) / abs(cpu_val), "rtol_target": 1e-10}
     return {
+        **parity,
         "value": 1.0 / t_full,
         "unit": "evals/s",
         "cores": int(threads),
@@ -122,7 +136,7 @@ def cpu_baseline(N, d, kernel, full=True):
                   f"({Ns ** 3 / 3 / t_chol * 1e-9:.0f} GFLOP/s) solve {t_solve:.3f}s -> {t_full:.1f}s per eval; "
                   f"BLAS threads {threads} of {os.cpu_count()} machine cores (the one-GPU box's CPU share)",
         "lml_grad_value": 1.0 / t_grad,
-        "lml_grad_sample": f"oracle LML+grad at N={Ng}, scaled by (N/{Ng})^3 -> {t_grad:.0f}s per eval",
+        "lml_grad_sample": f"oracle LML+grad measured at N={Ng} ({t_grad_meas:.1f}s), scaled by (N/{Ng})^3 -> {t_grad:.0f}s per eval",
     }
 
 
@@ -374,7 +388,9 @@ def main():
     # panel kernels that overlap it in the timed region.
     acc = {"assemble_ms": 0.0, "cholesky_ms": 0.0, "gemm_ms": 0.0, "gemm_flops": 0.0, "gemm_launches": 0.0, "total_ms": 0.0,
            "gemm_b_ms": 0.0, "gemm_b_flops": 0.0, "gemm_b_launches": 0.0}
+    insitu = dict(acc)  # the same events with look-ahead ON: the dominant kernel next to the panel chain of the second stream
     rsteps = max(1, min(args.roofline_steps, args.steps))
+    gpu_ref_lml = None
     if rank == 0:
         gp.set_option(0, 0)
         gp.set_profiling(2)
@@ -383,8 +399,15 @@ def main():
             tm = gp.timers()
             for k in acc:
                 acc[k] += tm[k]
-        gp.set_profiling(0)
         gp.set_option(0, 0 if args.no_lookahead else 1)
+        for i in range(rsteps):
+            gp.lml(thetas[args.warmup + i])
+            tm = gp.timers()
+            for k in insitu:
+                insitu[k] += tm[k]
+        gp.set_profiling(0)
+        # parity record: the device's LML at the theta (and seed-0 data) the CPU baseline evaluates below
+        gpu_ref_lml = gp.lml(reference_theta(d))
     gp.close()
     del gp
     torch.cuda.empty_cache()
@@ -405,7 +428,7 @@ def main():
                 traffic = tj.get("hbm_bytes_per_launch")
                 src = os.path.join(ROOT, "andvaranaut_amd", "csrc", "gemm_f64.hip")
                 sha = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
-                traffic_note = ("PMC passes of tools/pmc_traffic.sh on this kernel source" if tj.get("gemm_src_sha16") == sha
+                traffic_note = ("PMC passes of tools/prof_round.sh + tools/pmc_traffic.py on this kernel source" if tj.get("gemm_src_sha16") == sha
                                 else f"STALE: measured on gemm_f64.hip {tj.get('gemm_src_sha16')}, current {sha}")
             except Exception as e:  # noqa: BLE001
                 traffic_note = f"unreadable: {e}"
@@ -441,18 +464,27 @@ def main():
             "roofline": {"kernel": "gemm_f64_kernel_b (SYRK trailing/panel updates, v_mfma_f64_16x16x4_f64)",
                          "bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_note,
+                         # the same kernel inside the timed two-stream configuration (HIP events on its own stream, look-ahead
+                         # on: the panel chain's leaf / strip / in-panel kernels share the chip -- and the DP pipe -- with it)
+                         "in_situ_frac": (insitu["gemm_b_flops"] / (insitu["gemm_b_ms"] * 1e-3) * 1e-12 / FP64_PEAK_TFLOPS
+                                          if insitu["gemm_b_ms"] > 0 else None),
+                         "in_situ_avg_launch_ms": insitu["gemm_b_ms"] / max(insitu["gemm_b_launches"], 1.0),
+                         "in_situ_source": "HIP events around every launch on the main stream, look-ahead on, same thetas",
                          "avg_launch_ms": gemm_avg_ms, "launches_per_step": acc["gemm_b_launches"] / rsteps,
                          "flop_share_of_all_gemm": acc["gemm_b_flops"] / max(acc["gemm_flops"], 1.0),
                          "all_gemm_kernels_tflops": all_gemm, "all_gemm_launches_per_step": acc["gemm_launches"] / rsteps},
         }
 
-    # sharded sub-record (strong scaling, BASELINE config 4) under a deadline: the replicas' line survives a stuck exchange
+    # sharded sub-record (strong scaling, BASELINE config 4) under a deadline: the replicas' line survives a stuck
+    # exchange, but the PROCESS does not pretend to be healthy -- a watchdog or a caught failure ends with a non-zero
+    # exit status once the line is out (nothing is retried or restarted in-process).
+    exit_code = 0
     if not args.no_sharded:
         def expire():
             if rank == 0 and line is not None:
                 line["sharded"] = {"error": f"not finished after {args.sharded_timeout:.0f} s (rank 0 gave up waiting)"}
                 print(json.dumps(line), flush=True)
-            os._exit(0)  # every rank leaves cleanly: the replicas' line stands on its own
+            os._exit(3)
 
         with Deadline(args.sharded_timeout, expire):
             try:
@@ -460,16 +492,22 @@ def main():
                                      args.sharded_steps, 1)
             except Exception as e:  # noqa: BLE001 - the replicas' numbers must still be reported
                 rec = {"error": f"{type(e).__name__}: {e}"}
+                exit_code = 4
         if rank == 0:
             line["sharded"] = rec
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(N, d, args.kernel, full=not args.cpu_baseline_sample)
+            line["cpu_baseline"] = cpu_baseline(N, d, args.kernel, full=not args.cpu_baseline_sample, gpu_lml=gpu_ref_lml)
         print(json.dumps(line), flush=True)
+    if exit_code:
+        # a rank whose sharded step failed must not walk into the final barrier: its peers may be stuck inside the
+        # collective it left, and they leave through their own watchdog (exit 3)
+        sys.stdout.flush()
+        os._exit(exit_code)
     # rank 0's roofline pass / CPU baseline run after the timed region: leave together -- but never hang on a rank that
     # died in the sharded sub-record after the line was printed
-    with Deadline(1800.0 if world == 1 else 120.0, lambda: os._exit(0)):
+    with Deadline(1800.0 if world == 1 else 120.0, lambda: os._exit(3)):
         dist.barrier()
         dist.destroy_process_group()
 

@@ -35,8 +35,10 @@ print(json.dumps({"rank": rank, "panels_owned": {k: v[2] for k, v in out.items()
 '''
 world = int(sys.argv[1])
 assert 1 <= world <= 6
-path = "/tmp/rehearse_worker.py"
-open(path, "w").write(WORKER)
+import tempfile
+fd, path = tempfile.mkstemp(prefix="rehearse_worker_", suffix=".py")  # concurrent rehearsals must not share a worker file
+with os.fdopen(fd, "w") as fh:
+    fh.write(WORKER)
 with socket.socket() as s:
     s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
 procs = []

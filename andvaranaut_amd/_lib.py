@@ -34,6 +34,29 @@ class MiGpBuffers(ctypes.Structure):
     ]
 
 
+class MiGpShardConfig(ctypes.Structure):
+    _fields_ = [
+        ("n", ctypes.c_int),
+        ("d", ctypes.c_int),
+        ("nkern", ctypes.c_int),
+        ("kernel_ids", ctypes.c_int * MAX_KERN),
+        ("ops", ctypes.c_int * MAX_KERN),
+        ("panel_tiles", ctypes.c_int),
+        ("world", ctypes.c_int),
+        ("rank", ctypes.c_int),
+        ("device", ctypes.c_int),
+        ("X_dev", ctypes.c_void_p),
+        ("y_dev", ctypes.c_void_p),
+        ("K_dev", ctypes.c_void_p),
+        ("ldk", ctypes.c_long),
+        ("P_dev", ctypes.c_void_p * 2),
+        ("ldp", ctypes.c_long),
+        ("theta_dev", ctypes.c_void_p),
+        ("info_dev", ctypes.c_void_p),
+        ("out_dev", ctypes.c_void_p),
+    ]
+
+
 _lib = None
 
 
@@ -84,6 +107,15 @@ def load():
     lib.mi_gp_grad_contract_block_scratch.argtypes = [ci, ci, ci, ci]
     lib.mi_gp_grad_contract_block_scratch.restype = cl
     lib.mi_gp_grad_contract_block.argtypes = [ci, ci, ip, ip, vp, vp, ci, vp, cl, ci, ci, ci, vp, vp, cl, vp, vp]
+    lib.mi_gp_shard_create.argtypes = [ctypes.POINTER(MiGpShardConfig), ctypes.POINTER(vp)]
+    lib.mi_gp_shard_destroy.argtypes = [vp]
+    lib.mi_gp_shard_begin.argtypes = [vp, ci, vp, vp]
+    lib.mi_gp_shard_step.argtypes = [vp, ci, vp, vp]
+    lib.mi_gp_shard_finish.argtypes = [vp, vp, vp]
+    lib.mi_gp_shard_set_option.argtypes = [vp, ci, ci]
+    lib.mi_gp_shard_times.argtypes = [vp, dp, ci]
+    lib.mi_gp_shard_last_error.argtypes = [vp]
+    lib.mi_gp_shard_last_error.restype = ctypes.c_char_p
     for name in EXPORTS:
         getattr(lib, name)  # raises AttributeError if a declared symbol is missing
     _lib = lib
@@ -121,4 +153,12 @@ EXPORTS = [
     "mi_gp_trmv_upper",
     "mi_gp_grad_contract_block_scratch",
     "mi_gp_grad_contract_block",
+    "mi_gp_shard_create",
+    "mi_gp_shard_destroy",
+    "mi_gp_shard_begin",
+    "mi_gp_shard_step",
+    "mi_gp_shard_finish",
+    "mi_gp_shard_set_option",
+    "mi_gp_shard_times",
+    "mi_gp_shard_last_error",
 ]

@@ -101,6 +101,12 @@ static hipError_t panel_rec(double* A, long lda, int ntr, int c0, int w, double*
   return panel_rec(A, lda, ntr, c0 + w1, w2, dinv, info, col_base, st);
 }
 
+hipError_t migp::chol_panel_blocks(double* A, long lda, int row_tiles, int w_tiles, double* dinv, int* info, int col_base,
+                                   hipStream_t st) {
+  return panel_rec(A, lda, row_tiles, 0, w_tiles, dinv, info, col_base, st);
+}
+int migp::ensure_kernel_attributes() { return ensure_init(); }
+
 extern "C" int mi_gp_chol_panel(double* A_dev, long lda, int row_tiles, int w_tiles, double* dinv_dev, int* info_dev,
                                 int col_base, void* stream) {
   if (!A_dev || !dinv_dev || !info_dev || w_tiles <= 0 || row_tiles < w_tiles || (lda & 1)) {

@@ -9,6 +9,7 @@
 // columns of one row (two 16-byte stores instead of four 8-byte ones); exp and sqrt are branch-free fp64 sequences of
 // ~19 and ~10 instructions (<= 1 ulp, checked against libm over the argument range) instead of the libm calls.
 #include "migp_kernels.h"
+#include "migp_math.h"
 
 namespace migp {
 
@@ -18,44 +19,6 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 constexpr int AT = 64;      // assembly tile
 constexpr int DCH = 32;     // input dimensions per LDS chunk (multiple of 4)
 constexpr int DLD = 36;     // LDS row stride in doubles: 4 mod 32, so 16 rows x 4 columns of a fragment read cover all bank pairs twice
-
-// exp(x) for x <= 0 (any magnitude): Cody-Waite reduction by ln 2 in two pieces, degree-13 Taylor polynomial on
-// |r| <= ln2 / 2 (remainder 4e-18 relative), ldexp.  Max error 1.0 ulp against libm over [-745, 0].
-__device__ __forceinline__ double exp_nonpos(double x) {
-  const double k = __builtin_rint(x * 1.4426950408889634);
-  double r = __builtin_fma(-k, 0.6931471803691238, x);
-  r = __builtin_fma(-k, 1.9082149292705877e-10, r);
-  double p = 1.6059043836821613e-10;                       // 1/13!
-  p = __builtin_fma(p, r, 2.08767569878681e-09);          // 1/12!
-  p = __builtin_fma(p, r, 2.505210838544172e-08);         // 1/11!
-  p = __builtin_fma(p, r, 2.755731922398589e-07);         // 1/10!
-  p = __builtin_fma(p, r, 2.7557319223985893e-06);        // 1/9!
-  p = __builtin_fma(p, r, 2.48015873015873e-05);          // 1/8!
-  p = __builtin_fma(p, r, 0.0001984126984126984);         // 1/7!
-  p = __builtin_fma(p, r, 0.001388888888888889);          // 1/6!
-  p = __builtin_fma(p, r, 0.008333333333333333);          // 1/5!
-  p = __builtin_fma(p, r, 0.041666666666666664);          // 1/4!
-  p = __builtin_fma(p, r, 0.16666666666666666);           // 1/3!
-  p = __builtin_fma(p, r, 0.5);
-  p = __builtin_fma(p, r, 1.0);
-  p = __builtin_fma(p, r, 1.0);
-  const int ki = (k < -2000.0) ? -2000 : (int)k;           // deep underflow: ldexp returns 0 either way
-  return __builtin_amdgcn_ldexp(p, ki);
-}
-
-// sqrt(t) for normal t > 0: v_rsq_f64 seed, two Goldschmidt steps, one Newton correction (<= 1 ulp)
-__device__ __forceinline__ double sqrt_pos(double t) {
-  const double y = __builtin_amdgcn_rsq(t);
-  double g = t * y, h = 0.5 * y;
-  double e = __builtin_fma(-h, g, 0.5);
-  g = __builtin_fma(g, e, g);
-  h = __builtin_fma(h, e, h);
-  e = __builtin_fma(-h, g, 0.5);
-  g = __builtin_fma(g, e, g);
-  h = __builtin_fma(h, e, h);
-  const double dd = __builtin_fma(-g, g, t);
-  return __builtin_fma(dd, h, g);
-}
 
 __device__ __forceinline__ double base_kernel_eval(int kid, double r2, double alpha) {
   switch (kid) {

@@ -87,6 +87,26 @@ __device__ __forceinline__ void tile_from_index_banded(const GemmParams& p, int 
   tile_from_index_banded(p.tri, p.mt, p.nt, idx, R, ti, tj);
 }
 
+// Panel-list mode (GemmParams::pl): tile `idx` of the launch -> tile-unit coordinates of its A rows, B rows, C rows and C
+// columns, and whether it is a diagonal tile of its panel's trapezoid.  The table walk is uniform per workgroup (scalar loads).
+__device__ __forceinline__ void list_tile(const GemmParams& p, int idx, int& ra, int& rb, int& rc, int& cc, bool& diag) {
+  const int want = idx + p.pl[p.pl_first].x;
+  int lo = p.pl_first, hi = p.pl_first + p.pl_n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (p.pl[mid].x <= want) lo = mid; else hi = mid - 1;
+  }
+  const int4 d = p.pl[lo];
+  int ti, tj;
+  if (p.band > 0) tile_from_index_banded(1, p.pl_rows - d.y, d.w, want - d.x, p.band, ti, tj);
+  else tile_from_index(1, d.w, want - d.x, ti, tj);
+  ra = d.y - p.pl_abase + ti;
+  rb = d.y - p.pl_abase + tj;
+  rc = d.y + ti;
+  cc = d.z + tj;
+  diag = (ti == tj);
+}
+
 // ---------------------------------------------------------------------------------------------
 // 128x128 tiles: 256-thread workgroups (4 waves as 2x2, 64x64 per wave = 4x4 MFMA tiles, 64 accumulator
 // doubles per lane), K chunks of 16, 72 KiB of LDS -> TWO workgroups per CU whose barriers, prologues
@@ -148,11 +168,19 @@ __global__ __launch_bounds__(vb::NT_B, 2) void gemm_f64_kernel_b(GemmParams p) {
     idx = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
   }
   int ti, tj;
-  // (full rectangles measured neutral: 8192^3 75.2 vs 75.7 TFLOP/s -- the row-major order stays for them)
-  if (p.band > 0 && p.tri && p.kmode == 0) tile_from_index_banded(p, idx, p.band, ti, tj);
-  else tile_from_index(p, idx, ti, tj);
-  if (p.kmode == 2) ti = p.mt - 1 - ti;
-  if (p.kmode == 4 && !p.tri) { tj = p.nt - 1 - idx / p.mt; ti = idx % p.mt; }  // longest-k columns first (LPT order)
+  int rc, cc;  // C tile row / column (differ from the operand rows ti / tj only in panel-list mode)
+  if (p.pl) {
+    bool diag;
+    list_tile(p, idx, ti, tj, rc, cc, diag);
+  } else {
+    // (full rectangles measured neutral: 8192^3 75.2 vs 75.7 TFLOP/s -- the row-major order stays for them)
+    if (p.band > 0 && p.tri && p.kmode == 0) tile_from_index_banded(p, idx, p.band, ti, tj);
+    else tile_from_index(p, idx, ti, tj);
+    if (p.kmode == 2) ti = p.mt - 1 - ti;
+    if (p.kmode == 4 && !p.tri) { tj = p.nt - 1 - idx / p.mt; ti = idx % p.mt; }  // longest-k columns first (LPT order)
+    rc = ti;
+    cc = tj;
+  }
   const int i0 = ti * TILE, j0 = tj * TILE;
   int kbeg = 0, kend = p.k;
   if (p.kmode == 1) kbeg = j0;
@@ -224,7 +252,7 @@ __global__ __launch_bounds__(vb::NT_B, 2) void gemm_f64_kernel_b(GemmParams p) {
   // place of those chunks' global prefetches, which would be redundant reloads), so that their round trip hides under
   // 128 MFMAs instead of following the loop
   const double alpha = p.alpha, beta = p.beta;
-  double* cbase = C + (long)(i0 + wr * 64 + kq) * p.ldc + j0 + wc * 64 + l15;
+  double* cbase = C + (long)(rc * TILE + wr * 64 + kq) * p.ldc + cc * TILE + wc * 64 + l15;
   double4_t cv[2][4];
   auto load_group = [&](int set, int a) {
 #pragma unroll
@@ -381,20 +409,36 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel_s(GemmParams p) {
   const int wr = wave >> 1, wc = wave & 1;
 
   int ti, tj;
-  if (p.sub_base >= 0) {
-    // tail of a 128x128-tile launch: this workgroup is one quadrant of parent tile sub_base + blockIdx.x / 4
-    int pti, ptj;
-    const int pidx = p.sub_base + ((int)blockIdx.x >> 2), quad = (int)blockIdx.x & 3;
-    if (p.band > 0 && p.tri) tile_from_index_banded(p.tri, p.sub_mt, p.sub_nt, pidx, p.band, pti, ptj);
-    else tile_from_index(p.tri, p.sub_nt, pidx, pti, ptj);
-    ti = 2 * pti + (quad >> 1);
-    tj = 2 * ptj + (quad & 1);
-    if (p.tri && tj > ti) return;  // the quadrant above the diagonal of a diagonal parent tile
+  int rc, cc;  // C tile row / column in 64-row units (differ from the operand rows ti / tj only in panel-list mode)
+  if (p.pl) {
+    // panel-list launch (or the tail of one): this workgroup is one quadrant of 128x128 tile sub_base + blockIdx.x / 4
+    int ra, rb, prc, pcc;
+    bool diag;
+    const int quad = (int)blockIdx.x & 3;
+    list_tile(p, p.sub_base + ((int)blockIdx.x >> 2), ra, rb, prc, pcc, diag);
+    if (diag && quad == 1) return;  // the quadrant above the diagonal of a diagonal tile
+    ti = 2 * ra + (quad >> 1);
+    tj = 2 * rb + (quad & 1);
+    rc = 2 * prc + (quad >> 1);
+    cc = 2 * pcc + (quad & 1);
   } else {
-    tile_from_index(p, blockIdx.x, ti, tj);
+    if (p.sub_base >= 0) {
+      // tail of a 128x128-tile launch: this workgroup is one quadrant of parent tile sub_base + blockIdx.x / 4
+      int pti, ptj;
+      const int pidx = p.sub_base + ((int)blockIdx.x >> 2), quad = (int)blockIdx.x & 3;
+      if (p.band > 0 && p.tri) tile_from_index_banded(p.tri, p.sub_mt, p.sub_nt, pidx, p.band, pti, ptj);
+      else tile_from_index(p.tri, p.sub_nt, pidx, pti, ptj);
+      ti = 2 * pti + (quad >> 1);
+      tj = 2 * ptj + (quad & 1);
+      if (p.tri && tj > ti) return;  // the quadrant above the diagonal of a diagonal parent tile
+    } else {
+      tile_from_index(p, blockIdx.x, ti, tj);
+    }
+    if (p.kmode == 2) ti = p.mt - 1 - ti;
+    if (p.kmode == 4 && !p.tri) { tj = p.nt - 1 - (int)blockIdx.x / p.mt; ti = (int)blockIdx.x % p.mt; }  // longest-k columns first (LPT order)
+    rc = ti;
+    cc = tj;
   }
-  if (p.kmode == 2) ti = p.mt - 1 - ti;
-  if (p.kmode == 4 && !p.tri) { tj = p.nt - 1 - (int)blockIdx.x / p.mt; ti = (int)blockIdx.x % p.mt; }  // longest-k columns first (LPT order)
   const int i0 = ti * TS, j0 = tj * TS;
   int kbeg = 0, kend = p.k;
   if (p.kmode == 1) kbeg = j0;
@@ -455,7 +499,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel_s(GemmParams p) {
   // C tile early: these launches are latency-bound, the read hides under the whole k loop
   const int kq = lane >> 4, l15 = lane & 15;
   const double alpha = p.alpha, beta = p.beta;
-  double* cbase = C + (long)(i0 + wr * 32 + kq) * p.ldc + j0 + wc * 32 + l15;
+  double* cbase = C + (long)(rc * TS + wr * 32 + kq) * p.ldc + cc * TS + wc * 32 + l15;
   double4_t cv[2][2];
   if (beta != 0.0) {
 #pragma unroll
@@ -554,6 +598,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel_s(GemmParams p) {
 constexpr size_t LDS_ONE_PER_CU = 82432;  // > half a CU (one workgroup per CU) and <= 160 KB - the 79 KB leaf image
 
 static int tile_count(const GemmParams& p) {
+  if (p.pl) return p.pl_tiles;
   if (!p.tri) return p.mt * p.nt;
   return p.nt * (p.nt + 1) / 2 + (p.mt - p.nt) * p.nt;
 }
@@ -591,6 +636,9 @@ hipError_t launch_gemm_f64(const GemmParams& p, int opA_kmajor, int opB_kmajor, 
       q.sub_mt = p.mt;
       q.sub_nt = p.nt;
       nwg = 4 * ntail;
+    } else if (p.pl) {  // a whole panel-list launch on 64x64 tiles: four quadrant workgroups per 128x128 tile
+      q.sub_base = 0;
+      nwg = 4 * nblk;
     }
     dim3 grid(nwg, 1, batch), block(256);
     // one_per_cu: unused dynamic LDS on top of the 60 KB static image pushes the request over half a CU

@@ -9,6 +9,7 @@
 // The reference obtains the gradient by reverse-mode autodiff through the PyTensor graph inside
 // pm.find_MAP / pm.sample (gpmcmc.py:345,351); the analytic form is restated in oracle/gp_oracle.py.
 #include "migp_kernels.h"
+#include "migp_math.h"
 
 namespace migp {
 
@@ -78,28 +79,30 @@ __global__ __launch_bounds__(256) void trmv_upper_t_kernel(const double* __restr
 __device__ __forceinline__ void base_kernel_val_der(int kid, double r2, double alpha, double& k, double& dk,
                                                     double& dalpha) {
   dalpha = 0.0;
-  if (kid == KID_RBF) {
-    k = exp(-0.5 * r2);
-    dk = -0.5 * k;
-  } else if (kid == KID_RATQUAD) {
+  if (kid == KID_RATQUAD) {
     const double u = 0.5 * r2 / alpha;
     k = pow(1.0 + u, -alpha);
     dk = -0.5 * k / (1.0 + u);
     dalpha = k * (-log1p(u) + u / (1.0 + u));
+    return;
+  }
+  // the four exponential families share ONE exp evaluation: e = exp(-rate * s), s = r2 (RBF) or r = sqrt(r2 + 1e-12)
+  const bool rbf = kid == KID_RBF;
+  const double r = rbf ? 0.0 : sqrt_pos(r2 + 1e-12);
+  const double rate = rbf ? 0.5 : kid == KID_MATERN52 ? 2.23606797749979 : kid == KID_MATERN32 ? 1.7320508075688772 : 0.5;
+  const double e = exp_nonpos(-1.0 * rate * (rbf ? r2 : r));
+  if (rbf) {
+    k = e;
+    dk = -0.5 * e;
+  } else if (kid == KID_MATERN52) {
+    k = (1.0 + 2.23606797749979 * r + 5.0 / 3.0 * (r * r)) * e;
+    dk = -(5.0 / 6.0) * (1.0 + 2.23606797749979 * r) * e;
+  } else if (kid == KID_MATERN32) {
+    k = (1.0 + 1.7320508075688772 * r) * e;
+    dk = -1.5 * e;
   } else {
-    const double r = sqrt(r2 + 1e-12);
-    if (kid == KID_MATERN52) {
-      const double e = exp(-2.23606797749979 * r);
-      k = (1.0 + 2.23606797749979 * r + 5.0 / 3.0 * (r * r)) * e;
-      dk = -(5.0 / 6.0) * (1.0 + 2.23606797749979 * r) * e;
-    } else if (kid == KID_MATERN32) {
-      const double e = exp(-1.7320508075688772 * r);
-      k = (1.0 + 1.7320508075688772 * r) * e;
-      dk = -1.5 * e;
-    } else {
-      k = exp(-0.5 * r);
-      dk = -0.25 * k / r;
-    }
+    k = e;
+    dk = -0.25 * e / r;
   }
 }
 
@@ -452,6 +455,11 @@ __global__ __launch_bounds__(256) void grad_x_kernel(KernSpec spec, const double
             if (spec.op[c2 - 1] == 1) coef *= kval[c2];
           cf[c][a][b] = w * coef * dkv[c];
         }
+        // one micro-tile element at a time: left to itself the scheduler interleaves all sixteen exp / sqrt chains of every
+        // component, the kernel sits at 256 VGPRs + spilled SGPRs, and with the inlined exp sequence of migp_math.h that
+        // build returned garbage in dLML/dX (round 3: nondeterministic, 1e38-sized entries; the libm build at 248 VGPRs did
+        // not) -- tests/test_gpu_data_grad.py repeats the four-component case to catch a regression
+        __builtin_amdgcn_sched_barrier(0);
       }
     // pass 2, one component at a time through the LDS tile
 #pragma unroll

@@ -28,6 +28,15 @@ struct GemmParams {
   // set by the launcher for that second launch: 64x64 tile 4 e + quadrant belongs to 128x128 tile sub_base + e of the
   // parent enumeration (sub_mt x sub_nt tiles of 128); -1: off
   int sub_base = -1, sub_mt = 0, sub_nt = 0;
+  // Panel-list mode (pl != nullptr; sharded driver, api_shard.hip): ONE launch updates the lower trapezoids of pl_n column
+  // panels of a block-cyclically distributed matrix, C_e -= P[rows >= g_e] P[rows of panel e]^T for e = pl_first ...
+  // pl[e] = {cum, g, ccol, w}: 128x128 tiles of the panels before e, global tile row of panel e's diagonal block, tile
+  // column of its first column in C (local storage), width in tile columns; pl[count].cum closes the table.  C's rows are
+  // global rows; A = B = the row-panel buffer whose row 0 is global tile row pl_abase; pl_rows = global tile rows (with the
+  // y block).  NT form, kmode 0, alpha/beta as given.  mt / nt are ignored.
+  const int4* pl = nullptr;
+  int pl_first = 0, pl_n = 0, pl_abase = 0, pl_rows = 0;
+  int pl_tiles = 0;  // pl[pl_first + pl_n].cum - pl[pl_first].cum (the host knows the table)
 };
 // opX_kmajor = 0: operand stored [x][k] (A row-major m x k / B stored n x k, i.e. "B^T");
 // opX_kmajor = 1: operand stored [k][x].
@@ -103,5 +112,10 @@ hipError_t launch_predict_reduce(const double* A, long lda, const double* beta, 
 // ---------------------------------------------------------------- api_blocks.hip
 // text behind mi_gp_last_global_error() (calls that have no handle to carry it: mi_gp_create, the block-level entries)
 void set_global_error(const char* text);
+// leaf + strip + in-panel updates of the w_tiles leading tile columns of a (row_tiles x w_tiles)-tile lower trapezoid
+// (the body of mi_gp_chol_panel)
+hipError_t chol_panel_blocks(double* A, long lda, int row_tiles, int w_tiles, double* dinv, int* info, int col_base,
+                             hipStream_t st);
+int ensure_kernel_attributes();  // per-device dynamic-LDS limits of the GEMM / leaf kernels; 0 or a C-ABI error code
 
 }  // namespace migp

@@ -45,19 +45,39 @@ def panel_tiles(ntc, world):
     return 8 if ntc >= 32 * world else 4
 
 
+class _Arrived:
+    """Stand-in for a collective's work handle (emulation): wait() orders the current stream behind the panel's arrival."""
+
+    def __init__(self, dev, ev):
+        self.dev, self.ev = dev, ev
+
+    def wait(self):
+        torch.cuda.current_stream(self.dev).wait_event(self.ev)
+
+
 class DistGP:
     """A GP data set whose covariance is column-panel sharded over the ranks of the default process
-    group (or a single process when torch.distributed is not initialised)."""
+    group (or a single process when torch.distributed is not initialised).
 
-    def __init__(self, X, y, kernel="RBF", device=None, panel_width_tiles=None):
+    ``emulate=(world, rank)``: this single process plays rank ``rank`` of a ``world``-rank job -- it owns, updates and
+    factors exactly that rank's panels; the panels other ranks would broadcast are copied in from a complete factor
+    (``set_factor_source``) on a stand-in "link" stream.  tools/emulate_rank.py uses it to measure a rank's compute path
+    and owner chain on one GPU before a multi-GPU node is available."""
+
+    def __init__(self, X, y, kernel="RBF", device=None, panel_width_tiles=None, emulate=None):
         if not torch.cuda.is_available():
             raise RuntimeError("DistGP needs ROCm GPUs: the GP hot path has no CPU implementation")
         self.lib = _lib.load()
-        self.rank = dist.get_rank() if dist.is_initialized() else 0
-        self.world = dist.get_world_size() if dist.is_initialized() else 1
-        # With a process group the exchange steps are always issued (a one-rank group included: the RCCL call path is
-        # then the one a multi-GPU run takes); without one there is nothing to exchange.
-        self.collective = dist.is_initialized()
+        self.emulate = emulate is not None
+        if self.emulate:
+            self.world, self.rank = int(emulate[0]), int(emulate[1])
+            self.collective = False
+        else:
+            self.rank = dist.get_rank() if dist.is_initialized() else 0
+            self.world = dist.get_world_size() if dist.is_initialized() else 1
+            # With a process group the exchange steps are always issued (a one-rank group included: the RCCL call path is
+            # then the one a multi-GPU run takes); without one there is nothing to exchange.
+            self.collective = dist.is_initialized()
         self.bytes_broadcast = 0
         X = np.ascontiguousarray(X, dtype=np.float64)
         y = np.ascontiguousarray(np.asarray(y, dtype=np.float64).reshape(-1))
@@ -82,14 +102,40 @@ class DistGP:
             self.K = torch.zeros((rows, self.ld), dtype=torch.float64, device=self.dev)
             self.P = [torch.zeros((rows + DINV_ROWS, self.ldbuf), dtype=torch.float64, device=self.dev) for _ in range(2)]
             self.theta_t = torch.zeros(self.ntheta, dtype=torch.float64, device=self.dev)
-            self.dinv = torch.zeros(self.pwt * MINV, dtype=torch.float64, device=self.dev)
             self.info = torch.zeros(4, dtype=torch.int32, device=self.dev)
             self.out = torch.zeros(16, dtype=torch.float64, device=self.dev)
             # look-ahead inside the rank: the owner of the next panel updates, factors and stages it on this stream while
-            # its bulk updates with the current panel run on the main stream (round 2; one rank, N = 65536: see DESIGN.md)
+            # its bulk updates with the current panel run on the main stream
             self.side = torch.cuda.Stream(device=self.dev)
+            self.link = torch.cuda.Stream(device=self.dev) if self.emulate else None  # stands in for RCCL's own stream
         self.kids = (ctypes.c_int * _lib.MAX_KERN)(*[_lib.KERNEL_IDS[k] for k in self.kerns] + [0] * (_lib.MAX_KERN - self.nkern))
         self.opids = (ctypes.c_int * _lib.MAX_KERN)(*[_lib.OP_IDS[o] for o in self.ops] + [0] * (_lib.MAX_KERN - len(self.ops)))
+        # everything of a panel step except the exchange sits behind one C entry (mi_gp_shard_step)
+        cfg = _lib.MiGpShardConfig()
+        cfg.n, cfg.d, cfg.nkern = self.n, self.d, self.nkern
+        for i in range(_lib.MAX_KERN):
+            cfg.kernel_ids[i], cfg.ops[i] = self.kids[i], self.opids[i]
+        cfg.panel_tiles, cfg.world, cfg.rank, cfg.device = self.pwt, self.world, self.rank, self.dev.index
+        cfg.X_dev, cfg.y_dev, cfg.K_dev, cfg.ldk = self.X_t.data_ptr(), self.y_t.data_ptr(), self.K.data_ptr(), self.ld
+        cfg.P_dev[0], cfg.P_dev[1], cfg.ldp = self.P[0].data_ptr(), self.P[1].data_ptr(), self.ldbuf
+        cfg.theta_dev, cfg.info_dev, cfg.out_dev = self.theta_t.data_ptr(), self.info.data_ptr(), self.out.data_ptr()
+        self.sh = ctypes.c_void_p()
+        r = self.lib.mi_gp_shard_create(ctypes.byref(cfg), ctypes.byref(self.sh))
+        if r != 0:
+            raise RuntimeError(f"mi_gp_shard_create failed ({r}): {self.lib.mi_gp_shard_last_error(None).decode()}")
+        self.source = None
+        self.link_ms = 0.0
+
+    def close(self):
+        if getattr(self, "sh", None):
+            self.lib.mi_gp_shard_destroy(self.sh)
+            self.sh = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
 
     # ------------------------------------------------------------------ helpers
     def _w(self, j):
@@ -99,51 +145,31 @@ class DistGP:
         if r != 0:
             raise RuntimeError(f"{what} failed ({r}): {self.lib.mi_gp_last_global_error().decode()}")
 
+    def _scheck(self, r, what):
+        if r != 0:
+            raise RuntimeError(f"{what} failed ({r}): {self.lib.mi_gp_shard_last_error(self.sh).decode()}")
+
     def _ptr(self, t, row, col):
         return t.data_ptr() + 8 * (row * t.stride(0) + col)
 
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
 
-    def _assemble(self, j, noise_form):
-        li, w = self.local_index[j], self._w(j)
-        r0 = c0 = j * self.pw
-        nrows, ncols = max(0, self.n - r0), max(0, min(self.n - c0, w * 128))
-        self._check(self.lib.mi_gp_assemble_block(
-            self.d, self.nkern, self.kids, self.opids, self.theta_t.data_ptr(),
-            self.X_t.data_ptr() + 8 * r0 * self.d, nrows, self.X_t.data_ptr() + 8 * c0 * self.d, ncols, r0, c0,
-            self._ptr(self.K, r0, li * self.pw), self.ld, self.np_ - r0, w * 128, noise_form, self._stream()),
-            "mi_gp_assemble_block")
-        yr = self.K[self.np_:, li * self.pw: li * self.pw + w * 128]
-        yr.zero_()
-        if ncols > 0:
-            yr[0, :ncols] = self.y_t[c0: c0 + ncols]
+    def set_option(self, what, value):
+        """mi_gp_shard_set_option: 0 bulk updates one workgroup per CU beside the chain, 1 per-step events, 2 early update."""
+        self._scheck(self.lib.mi_gp_shard_set_option(self.sh, int(what), int(value)), "mi_gp_shard_set_option")
 
-    def _factor(self, j):
-        li, w = self.local_index[j], self._w(j)
-        r0 = j * self.pw
-        self._check(self.lib.mi_gp_chol_panel(self._ptr(self.K, r0, li * self.pw), self.ld, (self.np_ + 128 - r0) // 128, w,
-                                              self.dinv.data_ptr(), self.info.data_ptr(), r0, self._stream()),
-                    "mi_gp_chol_panel")
+    def step_times(self):
+        """[npan + 1][4] ms: update / factor / stage (side stream) and bulk (main stream) of every step of the last
+        evaluation (needs set_option(1, 1)); row npan holds panel 0's factorisation and staging."""
+        buf = (ctypes.c_double * (4 * (self.npan + 1)))()
+        n = self.lib.mi_gp_shard_times(self.sh, buf, self.npan + 1)
+        return np.array(buf[: 4 * max(n, 0)]).reshape(-1, 4)
 
-    def _update(self, jt, j, buf):
-        """panel jt (owned) -= P_j[rows >= jt] P_j[rows of jt]^T, lower trapezoid only."""
-        li, wt, wj = self.local_index[jt], self._w(jt), self._w(j)
-        rt = jt * self.pw
-        m = self.np_ + 128 - rt
-        off = rt - j * self.pw  # row of panel jt's diagonal block inside the broadcast buffer
-        a_ptr = self._ptr(buf, off, 0)
-        self._check(self.lib.mi_gp_gemm_f64(0, 1, m, wt * 128, wj * 128, -1.0, a_ptr, self.ldbuf, a_ptr, self.ldbuf, 1.0,
-                                            self._ptr(self.K, rt, li * self.pw), self.ld, 1, 0, 1, 0, 0, 0, self._stream()),
-                    "mi_gp_gemm_f64")
-
-    def _stage(self, j, buf):
-        li, w = self.local_index[j], self._w(j)
-        r0 = j * self.pw
-        rows = self.np_ + 128 - r0
-        buf[:rows, : w * 128].copy_(self.K[r0:, li * self.pw: li * self.pw + w * 128])
-        # the leaf inverses travel with the panel (128 more rows): the gradient's triangular solves need them everywhere
-        buf[rows: rows + DINV_ROWS].view(-1)[: w * MINV].copy_(self.dinv[: w * MINV])
+    def set_factor_source(self, K_full, ld_full):
+        """emulation: a complete factor (padded n + 128 rows: L in the lower triangle, beta^T in row np) that the panels
+        of other ranks are copied from."""
+        self.source = (K_full, ld_full)
 
     # ------------------------------------------------------------------ evaluation
     def lml(self, theta, noise_form=0, _keep=False):
@@ -153,61 +179,34 @@ class DistGP:
             raise ValueError(f"theta must have {self.ntheta} entries")
         if _keep:
             self._alloc_grad_buffers()
+        lib, sh = self.lib, self.sh
+        owner = lambda j: j % self.world  # noqa: E731
         with torch.cuda.device(self.dev):
-            self.theta_t.copy_(torch.from_numpy(theta))
-            self.info.fill_(0x7F7F7F7F)
-            for j in self.own:
-                self._assemble(j, noise_form)
-            owner = lambda j: j % self.world  # noqa: E731
-            if owner(0) == self.rank:
-                self._factor(0)
-                self._stage(0, self.P[0])
-            work = self._bcast(0)
             main = torch.cuda.current_stream(self.dev)
-            staged = None  # event behind the side stream's staging of the panel the next step consumes
+            ms, ss = ctypes.c_void_p(main.cuda_stream), ctypes.c_void_p(self.side.cuda_stream)
+            self.theta_t.copy_(torch.from_numpy(theta))
+            self._scheck(lib.mi_gp_shard_begin(sh, noise_form, ms, ss), "mi_gp_shard_begin")
+            work = self._exchange(0)  # panel 0 was staged on the main stream by its owner
             for j in range(self.npan):
-                buf = self.P[j % 2]
-                if work is not None:
-                    work.wait()
-                if staged is not None:
-                    main.wait_event(staged)
-                    staged = None
-                if _keep:
-                    self._keep_panel(j, buf)
                 jn = j + 1
-                work = None
-                if jn < self.npan:
-                    if owner(jn) == self.rank:
-                        # everything queued on the main stream so far (the previous step's updates of panel jn, the reads
-                        # of the buffer that is about to be restaged) precedes the side stream's work
-                        ready = torch.cuda.Event()
-                        ready.record(main)
+                mine = jn < self.npan and owner(jn) == self.rank
+                if work is not None:
+                    work.wait()  # the main stream waits for panel j ...
+                    if mine:
                         with torch.cuda.stream(self.side):
-                            self.side.wait_event(ready)
-                            self._update(jn, j, buf)
-                            self._factor(jn)
-                            self._stage(jn, self.P[jn % 2])
-                            staged = torch.cuda.Event()
-                            staged.record(self.side)
-                            work = self._bcast(jn)  # posted behind the staging: RCCL orders itself after the side stream
-                    else:
-                        work = self._bcast(jn)  # posted before the bulk updates so that it overlaps them
-                for jt in self.own:
-                    if jt > jn:
-                        self._update(jt, j, buf)
-            main.wait_stream(self.side)
+                            work.wait()  # ... and so does the side stream, whose chain reads it first
+                work = None
+                if jn < self.npan and not mine:
+                    work = self._exchange(jn)  # posted before this step's launches so that it overlaps them
+                self._scheck(lib.mi_gp_shard_step(sh, j, ms, ss), "mi_gp_shard_step")
+                if mine:
+                    with torch.cuda.stream(self.side):
+                        work = self._exchange(jn)  # behind the staging: the transport orders itself after the side stream
+                if _keep:
+                    self._keep_panel(j, self.P[j % 2])
+            self._scheck(lib.mi_gp_shard_finish(sh, ms, ss), "mi_gp_shard_finish")
             # local pieces of sum log L_ii and |beta|^2, then one small all-reduce
-            acc = torch.zeros(3, dtype=torch.float64, device=self.dev)
-            for j in self.own:
-                li, w = self.local_index[j], self._w(j)
-                c0 = j * self.pw
-                nv = max(0, min(self.n - c0, w * 128))
-                if nv == 0:
-                    continue
-                self._check(self.lib.mi_gp_lml_partial(self._ptr(self.K, c0, li * self.pw), self.ld,
-                                                       self._ptr(self.K, self.np_, li * self.pw), nv, self.out.data_ptr(),
-                                                       self._stream()), "mi_gp_lml_partial")
-                acc[:2] += self.out[1:3]
+            acc = self.out[1:3].clone()
             info = self.info[:1].clone()
             if self.collective:
                 dist.all_reduce(acc, op=dist.ReduceOp.SUM)
@@ -217,7 +216,38 @@ class DistGP:
         if self.info_value != 0x7F7F7F7F:
             return -math.inf
         self.logdet, self.quad = logdet, quad
+        if self.emulate:
+            return float("nan")  # a single emulated rank holds only its share of the two sums
         return -0.5 * self.n * math.log(2.0 * math.pi) - 0.5 * quad - logdet
+
+    def _exchange(self, j):
+        """Post the exchange of panel j under the current stream: the RCCL broadcast from its owner, or -- emulating
+        another rank's panel -- a copy from the complete factor on the stand-in link stream.  Returns something with
+        .wait() (makes the then-current stream wait for the panel) or None when there is nothing to wait for."""
+        if self.collective:
+            return self._bcast(j)
+        if self.emulate:
+            if j % self.world != self.rank:
+                return self._standin(j)
+            # this rank's own panel: in a real run its broadcast completes behind the staging on the stream it was posted
+            # under, and work.wait() orders the main stream (and the next exchange into the partner buffer) behind it
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.dev))
+            return _Arrived(self.dev, ev)
+        return None
+
+    def _standin(self, j):
+        src, _ = self.source
+        w, r0 = self._w(j), j * self.pw
+        rows = self.np_ + 128 - r0
+        cur = torch.cuda.current_stream(self.dev)
+        self.link.wait_stream(cur)  # like the transport: ordered behind the stream the exchange was posted under
+        with torch.cuda.stream(self.link):
+            self.P[j % 2][:rows, : w * 128].copy_(src[r0: r0 + rows, r0: r0 + w * 128])
+            ev = torch.cuda.Event()
+            ev.record(self.link)
+        self.bytes_broadcast += (rows + DINV_ROWS) * self.ldbuf * 8
+        return _Arrived(self.dev, ev)
 
     def _bcast(self, j):
         if not self.collective:

@@ -222,6 +222,19 @@ def sharded_record(args, rank, world, dev, N, d, kernel, steps, warmup, grad=Fal
         "collectives": "rccl" if (dist.is_initialized() and dist.get_backend() == "nccl") else "none (single process)",
         "finite": bool(ok), "lml": float(vals[-1]),
     }
+    # the one-GPU rank emulation's prediction for this world size (tools/emulate_rank.py --curve), for the first hardware
+    # run to be checked against: a model (measured per-rank compute and owner chain + bytes / link bandwidth), not a result
+    mfile = os.path.join(ROOT, "profiles", "r03_sharded_model.json")
+    if not grad and os.path.exists(mfile):
+        try:
+            mj = json.load(open(mfile))
+            if mj.get("N") == N and mj.get("d") == d:
+                for pr in mj.get("prediction", []):
+                    if pr.get("world") == world:
+                        rec["predicted_ms_per_step"] = pr["predicted_ms"]
+                        rec["prediction_source"] = "profiles/r03_sharded_model.json (one-GPU emulation of ranks + link model)"
+        except Exception as e:  # noqa: BLE001
+            rec["prediction_source"] = f"unreadable: {e}"
     del gp
     torch.cuda.empty_cache()
     return rec
@@ -433,6 +446,16 @@ def main():
             except Exception as e:  # noqa: BLE001
                 traffic_note = f"unreadable: {e}"
         asm_bytes = 8.0 * (N // 64) * (N // 64 + 1) / 2 * 64 * 64 + 8.0 * N * d
+        asm_counter, asm_note = None, "no assemble record in profiles/gemm_traffic.json"
+        try:
+            aj = json.load(open(tfile)).get("assemble")
+            if aj:
+                asm_counter = aj["hbm_bytes_per_launch"]
+                asha = hashlib.sha256(open(os.path.join(ROOT, "andvaranaut_amd", "csrc", "assemble.hip"), "rb").read()).hexdigest()[:16]
+                asm_note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this bench (tools/prof_round.sh)" if aj.get("src_sha16") == asha
+                            else f"STALE: measured on assemble.hip {aj.get('src_sha16')}, current {asha}")
+        except Exception as e:  # noqa: BLE001
+            asm_note = f"unreadable: {e}"
         line = {
             "metric": "gp_lml_evals_per_s",
             "value": world * steps / elapsed,
@@ -460,7 +483,10 @@ def main():
             # K1/K2: lower-triangle 64x64 tiles written once + X read once (8*N*d): HBM-side figure the
             # north star asks for next to the MFMA one
             "assembly": {"kernel": "assemble_kernel", "ms": acc["assemble_ms"] / rsteps, "algorithmic_bytes": asm_bytes,
-                         "achieved_GBps": asm_bytes / (acc["assemble_ms"] / rsteps * 1e-3) * 1e-9, "peak_GBps": 8000.0},
+                         "achieved_GBps": asm_bytes / (acc["assemble_ms"] / rsteps * 1e-3) * 1e-9, "peak_GBps": 8000.0,
+                         # counter-derived: HBM bytes of one launch from the PMC passes / this run's launch time
+                         "hbm_bytes_counters": asm_counter, "hbm_bytes_source": asm_note,
+                         "counter_GBps": (asm_counter / (acc["assemble_ms"] / rsteps * 1e-3) * 1e-9) if asm_counter else None},
             "roofline": {"kernel": "gemm_f64_kernel_b (SYRK trailing/panel updates, v_mfma_f64_16x16x4_f64)",
                          "bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_note,

@@ -191,6 +191,55 @@ int mi_gp_grad_contract_block(int d, int nkern, const int* kernel_ids, const int
                               const double* alpha_dev, double* part_dev, long part_len, double* grad_dev,
                               void* hip_stream);
 
+/* ---- sharded factorisation, one call per panel step (SURVEY 8e second row; BASELINE config 4).  The covariance is
+ * distributed over `world` ranks in 1-D block-cyclic column panels of panel_tiles * 128 columns (panel j belongs to rank
+ * j % world); a rank stores its panels side by side (local column li * pw for its li-th panel) with GLOBAL rows.  The
+ * exchange itself (one broadcast of P_dev[j % 2] per panel) stays with the caller (torch.distributed / RCCL); these
+ * entries enqueue everything else of a step behind one call:
+ *   begin : assemble the owned panels (+ their y^T rows); the owner of panel 0 factors it and stages it into P_dev[0]
+ *   step j: panel j is complete in P_dev[j % 2] and visible to main_stream AND side_stream.  The owner of panel j+1 updates it with
+ *           panel j, factors it and stages it into P_dev[(j+1) % 2] on side_stream (the caller broadcasts it under that
+ *           stream); then ONE GEMM launch on main_stream updates every owned panel > j+1 (panel-list mode of the kernel)
+ *   finish: main_stream waits for side_stream; out_dev[1] = sum log L_ii, out_dev[2] = sum beta_i^2 over the owned panels
+ * A panel buffer holds rows r0 = j * pw .. np + 127 of the panel (np = padded n; rows np.. = the y^T block whose first
+ * row becomes beta^T), then 128 more rows whose flat leading panel_tiles * 16384 doubles are the leaf inverses (the
+ * sharded gradient needs them everywhere): (np + 256) rows x ldp >= pw + 16 doubles.
+ * world / rank need not be a process group's: a single process can play rank r of W (tools/emulate_rank.py).
+ * Replaces the per-panel LAPACK dpotrf steps behind pt.slinalg.cholesky (gpmcmc.py:313) at a size one GPU need not hold. */
+typedef struct mi_gp_shard mi_gp_shard;
+typedef struct {
+  int n, d, nkern;
+  int kernel_ids[MI_GP_MAX_KERN];
+  int ops[MI_GP_MAX_KERN];
+  int panel_tiles;         /* panel width in 128-column tiles */
+  int world, rank;
+  int device;
+  const double* X_dev;     /* n x d, replicated */
+  const double* y_dev;     /* n */
+  double* K_dev;           /* (np + 128) x ldk, ldk >= owned panels * pw, even */
+  long ldk;
+  double* P_dev[2];        /* panel buffers, (np + 256) x ldp each */
+  long ldp;
+  const double* theta_dev; /* C-ABI theta on the device (the caller uploads it before begin) */
+  int* info_dev;           /* [1] bad-pivot word: reset by begin, atomicMin(global column + 1) */
+  double* out_dev;         /* [4] scalars of finish */
+} mi_gp_shard_config;
+int mi_gp_shard_create(const mi_gp_shard_config* cfg, mi_gp_shard** out);
+int mi_gp_shard_destroy(mi_gp_shard* s);
+int mi_gp_shard_begin(mi_gp_shard* s, int noise_form, void* main_stream, void* side_stream);
+int mi_gp_shard_step(mi_gp_shard* s, int j, void* main_stream, void* side_stream);
+int mi_gp_shard_finish(mi_gp_shard* s, void* main_stream, void* side_stream);
+/* options: 0 bulk updates at one workgroup per CU while this rank's side stream factors the next panel (default 1);
+ *          1 record per-step HIP events (update / factor / stage on the side stream, bulk on the main stream);
+ *          2 update the panel this rank factors in the NEXT step first and alone, so that its chain does not wait for the
+ *            whole bulk update (default 1; that panel's update may run on the other tile size: agreement to rounding) */
+int mi_gp_shard_set_option(mi_gp_shard* s, int what, int value);
+/* per-step phase times of the last evaluation (option 1; call after synchronising): out[4 * j + 0..3] =
+ * update_ms, factor_ms, stage_ms, bulk_ms of step j (0 where the step had no such phase; factor of panel 0 is in
+ * out[4 * npanels + 1], its staging in out[4 * npanels + 2]); returns the number of steps written, < 0 on error */
+int mi_gp_shard_times(mi_gp_shard* s, double* out, int max_steps);
+const char* mi_gp_shard_last_error(mi_gp_shard* s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -182,3 +182,29 @@ def test_device_data_gradients_match_mpmath_golden():
             ref = np.array([[float(v) for v in row] for row in ref]) if key == "gX" else np.array([float(v) for v in ref])
             assert np.abs(got - ref).max() <= tol * max(np.abs(ref).max(), 1e-300), (c["name"], key)
         gp.close()
+
+
+@pytest.mark.parametrize("kernel,d", [("Exponential*Matern32+Matern32+RBF", 2), ("RBF+Matern52*Matern32+RBF", 3),
+                                      ("Matern52+RBF*RBF", 17), ("RBF+Matern32", 40)])
+def test_data_gradients_are_reproducible_for_every_component_count(kernel, d):
+    """Round-3 regression: a build of grad_x_kernel<4, 1> at 256 VGPRs + spilled SGPRs returned nondeterministic garbage
+    in dLML/dX (entries of 1e38, different on every call) while LML, dLML/dtheta and dLML/dy of the same evaluation were
+    right.  Fresh handles and repeated evaluations must return the same bits, and those must match the oracle."""
+    MiGP, orc = _mods()
+    N = 207
+    X, y = orc.synth_problem(N, d, seed=17)
+    kerns, ops = _split(kernel)
+    theta = orc.synth_theta(d, nkern=len(kerns), gv=1e-3)
+    theta[: len(kerns) * d] *= np.sqrt(d / 2.0)
+    _, _, gX_ref = orc.lml_grad_data(X, y, kerns, ops, theta)
+    first = None
+    for _ in range(3):
+        gp = MiGP(X, y, kernel)
+        for _ in range(3):
+            _, _, _, gX = gp.lml_grad_data(theta)
+            if first is None:
+                first = gX.copy()
+            assert np.array_equal(gX, first)
+        gp.close()
+    scale = np.maximum(np.abs(gX_ref), 1e-3 * np.abs(gX_ref).max())
+    assert np.max(np.abs(first - gX_ref) / scale) <= (1e-5 if "Exponential" in kernel else 1e-7)

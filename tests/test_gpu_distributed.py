@@ -146,3 +146,45 @@ def test_ranks_sharing_one_gpu_via_gloo(tmp_path, world):
     for p, (o, e) in zip(procs, outs):
         assert p.returncode == 0, e[-3000:]
     assert '"ok": true' in outs[0][0]
+
+
+@pytest.mark.parametrize("world,pwt,N", [(3, 2, 3000), (4, 1, 1700), (2, 4, 4200), (8, 2, 9000)])
+def test_emulated_ranks_partition_the_factorisation(world, pwt, N):
+    """Every rank of a `world`-rank job played in turn by one process (DistGP(emulate=...), the mode tools/emulate_rank.py
+    times): the panel-list GEMM launch then covers NON-contiguous panels (the gaps are other ranks' columns).  Each
+    rank's panels must equal the single-GPU factor's columns, and the ranks' partial log-det / quadratic-form sums must
+    add up to the single-GPU values."""
+    import torch
+
+    from andvaranaut_amd import MiGP
+    from andvaranaut_amd.distributed import DistGP
+    from oracle import gp_oracle as orc
+
+    d = 4
+    X, y = orc.synth_problem(N, d, seed=N)
+    theta = orc.synth_theta(d)
+    one = MiGP(X, y, "Matern52", need_grad=False)
+    ref = one.lml(theta)
+    logdet, quad = one.lml_parts()
+    K = one.K_t.clone()
+    one.close()
+    assert abs(ref - orc.lml(X, y, ["Matern52"], [], theta)) <= 1e-10 * abs(ref)
+    ld_sum = q_sum = 0.0
+    for rank in range(world):
+        gp = DistGP(X, y, "Matern52", panel_width_tiles=pwt, emulate=(world, rank))
+        gp.set_factor_source(K, K.stride(0))
+        for early in (1, 0):  # option 2 only reorders launches of the same arithmetic per panel
+            gp.set_option(2, early)
+            gp.lml(theta)
+            torch.cuda.synchronize()
+            for li, j in enumerate(gp.own):
+                w, r0 = gp._w(j), j * gp.pw
+                mine = torch.tril(gp.K[r0: gp.np_ + 1, li * gp.pw: li * gp.pw + w * 128], diagonal=0)
+                want = torch.tril(K[r0: gp.np_ + 1, r0: r0 + w * 128], diagonal=0)
+                err = (mine - want).abs().max().item()
+                assert err <= 1e-9, (world, rank, j, err)
+        ld_sum += gp.logdet
+        q_sum += gp.quad
+        gp.close()
+    assert abs(ld_sum - logdet) <= 1e-10 * abs(logdet), (ld_sum, logdet)
+    assert abs(q_sum - quad) <= 1e-9 * abs(quad), (q_sum, quad)

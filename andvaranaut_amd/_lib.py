@@ -114,6 +114,7 @@ def load():
     lib.mi_gp_shard_finish.argtypes = [vp, vp, vp]
     lib.mi_gp_shard_set_option.argtypes = [vp, ci, ci]
     lib.mi_gp_shard_times.argtypes = [vp, dp, ci]
+    lib.mi_gp_shard_chain_stream.argtypes = [vp]
     lib.mi_gp_shard_last_error.argtypes = [vp]
     lib.mi_gp_shard_last_error.restype = ctypes.c_char_p
     for name in EXPORTS:
@@ -160,5 +161,6 @@ EXPORTS = [
     "mi_gp_shard_finish",
     "mi_gp_shard_set_option",
     "mi_gp_shard_times",
+    "mi_gp_shard_chain_stream",
     "mi_gp_shard_last_error",
 ]

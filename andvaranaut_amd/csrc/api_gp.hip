@@ -608,7 +608,6 @@ extern "C" int mi_gp_alpha(mi_gp_handle* h, double* alpha_host) {
 extern "C" int mi_gp_grad_x(mi_gp_handle* h, double* gx_dev) {
   if (!h || !gx_dev) return -1;
   if (!h->have_kinv) { snprintf(h->err, sizeof(h->err), "mi_gp_grad_x: call mi_gp_lml_grad first"); return -1; }
-  if (h->cfg.d > 128) { snprintf(h->err, sizeof(h->err), "mi_gp_grad_x: d <= 128"); return -1; }
   HCK(hipSetDevice(h->device), "hipSetDevice");
   const int nsplit = grad_x_splits(h->n, h->cfg.d);
   if (nsplit > 1 && !h->gxs_dev)
@@ -731,7 +730,10 @@ extern "C" int mi_gp_predict_grad(mi_gp_handle* h, const double* Xnew_dev, int m
     snprintf(h->err, sizeof(h->err), "mi_gp_predict_grad needs Z_dev and W_dev in mi_gp_set_data");
     return -1;
   }
-  if (h->cfg.d > 128) { snprintf(h->err, sizeof(h->err), "mi_gp_predict_grad: d <= 128"); return -1; }
+  if ((size_t)(h->cfg.nkern + 1) * h->cfg.d * sizeof(double) > 61440) {
+    snprintf(h->err, sizeof(h->err), "mi_gp_predict_grad: (nkern + 1) * d must fit 61440 bytes of LDS (d <= %d here)", 7680 / (h->cfg.nkern + 1));
+    return -1;
+  }
   if (!h->factored) { snprintf(h->err, sizeof(h->err), "mi_gp_predict_grad: call mi_gp_factor first"); return -1; }
   if (!Xnew_dev || !work_dev || !mean_dev || !var_dev || m <= 0) return -1;
   if (ldw < h->np || (ldw & 1)) { snprintf(h->err, sizeof(h->err), "mi_gp_predict_grad: ldw must be even and >= padded n"); return -1; }

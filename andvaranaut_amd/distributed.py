@@ -156,7 +156,8 @@ class DistGP:
         return ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
 
     def set_option(self, what, value):
-        """mi_gp_shard_set_option: 0 bulk updates one workgroup per CU beside the chain, 1 per-step events, 2 early update."""
+        """mi_gp_shard_set_option: 0 bulk updates one workgroup per CU beside the chain, 1 per-step events, 2 early update,
+        3 chain on the main stream ahead of the bulk update (default on several ranks)."""
         self._scheck(self.lib.mi_gp_shard_set_option(self.sh, int(what), int(value)), "mi_gp_shard_set_option")
 
     def step_times(self):
@@ -187,12 +188,15 @@ class DistGP:
             self.theta_t.copy_(torch.from_numpy(theta))
             self._scheck(lib.mi_gp_shard_begin(sh, noise_form, ms, ss), "mi_gp_shard_begin")
             work = self._exchange(0)  # panel 0 was staged on the main stream by its owner
+            # the stream the owner's chain runs on (mi_gp_shard option 3): the side stream beside the bulk update on one
+            # rank, the main stream ahead of it on several
+            chain_stream = main if lib.mi_gp_shard_chain_stream(sh) == 1 else self.side
             for j in range(self.npan):
                 jn = j + 1
                 mine = jn < self.npan and owner(jn) == self.rank
                 if work is not None:
                     work.wait()  # the main stream waits for panel j ...
-                    if mine:
+                    if mine and chain_stream is not main:
                         with torch.cuda.stream(self.side):
                             work.wait()  # ... and so does the side stream, whose chain reads it first
                 work = None
@@ -201,7 +205,8 @@ class DistGP:
                 self._scheck(lib.mi_gp_shard_step(sh, j, ms, ss), "mi_gp_shard_step")
                 if mine:
                     with torch.cuda.stream(self.side):
-                        work = self._exchange(jn)  # behind the staging: the transport orders itself after the side stream
+                        # behind the staging (the side stream is ordered after it in both modes), not behind the bulk update
+                        work = self._exchange(jn)
                 if _keep:
                     self._keep_panel(j, self.P[j % 2])
             self._scheck(lib.mi_gp_shard_finish(sh, ms, ss), "mi_gp_shard_finish")

@@ -222,6 +222,10 @@ def sharded_record(args, rank, world, dev, N, d, kernel, steps, warmup, grad=Fal
         "collectives": "rccl" if (dist.is_initialized() and dist.get_backend() == "nccl") else "none (single process)",
         "finite": bool(ok), "lml": float(vals[-1]),
     }
+    gp_pwt = gp.pwt
+    gp.close()
+    del gp
+    torch.cuda.empty_cache()
     # the one-GPU rank emulation's prediction for this world size (tools/emulate_rank.py --curve), for the first hardware
     # run to be checked against: a model (measured per-rank compute and owner chain + bytes / link bandwidth), not a result
     mfile = os.path.join(ROOT, "profiles", "r03_sharded_model.json")
@@ -230,13 +234,12 @@ def sharded_record(args, rank, world, dev, N, d, kernel, steps, warmup, grad=Fal
             mj = json.load(open(mfile))
             if mj.get("N") == N and mj.get("d") == d:
                 for pr in mj.get("prediction", []):
-                    if pr.get("world") == world:
+                    # the model file holds both chain placements for world > 1; the driver's default is "ahead of the bulk update"
+                    if pr.get("world") == world and pr.get("panel_tiles") == gp_pwt and (world == 1 or pr.get("chain", "").startswith("on the main")):
                         rec["predicted_ms_per_step"] = pr["predicted_ms"]
                         rec["prediction_source"] = "profiles/r03_sharded_model.json (one-GPU emulation of ranks + link model)"
         except Exception as e:  # noqa: BLE001
             rec["prediction_source"] = f"unreadable: {e}"
-    del gp
-    torch.cuda.empty_cache()
     return rec
 
 

@@ -80,7 +80,8 @@ int mi_gp_lml_grad(mi_gp_handle* h, const double* theta_host, double* lml_out, d
  *   mi_gp_grad_x : dLML/dX (n x d row-major, device), dLML/dx_im = sum_j (alpha_i alpha_j - Kinv_ij) dK_ij/dx_im
  * They carry the chain rule through the output / input warps whose parameters the reference samples together
  * with the hyper-parameters (cwgp / iwgp, gpmcmc.py:211-279, Jacobian term :319) and through the free
- * observation rows of inverse_opt (gpmcmc.py:1096-1101,1156-1165); PyMC obtains both by autodiff.  d <= 128. */
+ * observation rows of inverse_opt (gpmcmc.py:1096-1101,1156-1165); PyMC obtains both by autodiff.  Any d (beyond 128 input
+ * dimensions mi_gp_grad_x runs one pass per window of 128 output dimensions). */
 int mi_gp_alpha(mi_gp_handle* h, double* alpha_host);
 int mi_gp_grad_x(mi_gp_handle* h, double* gx_dev);
 /* Optional per-point diagonal (n doubles, device, borrowed; NULL removes it) added to K on top of theta's
@@ -106,7 +107,8 @@ int mi_gp_predict_u(mi_gp_handle* h, const double* Xnew_dev, int m, double* work
 /* The same plus d mu / d x* and d var / d x* (m x d each, device): d mu = sum_i alpha_i dk(x_i,x*)/dx*,
  * d var = -2 sum_i w_i dk(x_i,x*)/dx* with w = K^-1 k(X,x*).  Replaces the PyTensor graph of the single-point
  * predictive that BO's refinement differentiates (gpmcmc.py:766-801).  Needs Z_dev / W_dev; work_dev must hold
- * 2 * ceil(m/128)*128 rows x ldw (the upper half receives the w rows); d <= 128. */
+ * 2 * ceil(m/128)*128 rows x ldw (the upper half receives the w rows); (nkern + 1) * d doubles must fit 60 KB of LDS
+ * (d <= 1536 with four components, 3840 with one). */
 int mi_gp_predict_grad(mi_gp_handle* h, const double* Xnew_dev, int m, double* work_dev, long ldw, double* mean_dev,
                        double* var_dev, int pred_noise, double* dmean_dev, double* dvar_dev);
 
@@ -232,12 +234,18 @@ int mi_gp_shard_finish(mi_gp_shard* s, void* main_stream, void* side_stream);
 /* options: 0 bulk updates at one workgroup per CU while this rank's side stream factors the next panel (default 1);
  *          1 record per-step HIP events (update / factor / stage on the side stream, bulk on the main stream);
  *          2 update the panel this rank factors in the NEXT step first and alone, so that its chain does not wait for the
- *            whole bulk update (default 1; that panel's update may run on the other tile size: agreement to rounding) */
+ *            whole bulk update (default 1; that panel's update may run on the other tile size: agreement to rounding);
+ *          3 the owner's chain (update + factor + stage of the next panel) runs on main_stream AHEAD of its bulk update
+ *            instead of beside it on side_stream (default: 1 when world > 1 -- every other rank waits for that chain, and
+ *            alone on the chip it is 2-3x shorter than next to a bulk update; 0 on one rank).  Either way side_stream is
+ *            ordered behind the staging when the call returns: the caller broadcasts the panel under side_stream. */
 int mi_gp_shard_set_option(mi_gp_shard* s, int what, int value);
 /* per-step phase times of the last evaluation (option 1; call after synchronising): out[4 * j + 0..3] =
  * update_ms, factor_ms, stage_ms, bulk_ms of step j (0 where the step had no such phase; factor of panel 0 is in
  * out[4 * npanels + 1], its staging in out[4 * npanels + 2]); returns the number of steps written, < 0 on error */
 int mi_gp_shard_times(mi_gp_shard* s, double* out, int max_steps);
+/* 0: the chain runs on side_stream (it must then wait for panel j as well), 1: on main_stream (option 3) */
+int mi_gp_shard_chain_stream(const mi_gp_shard* s);
 const char* mi_gp_shard_last_error(mi_gp_shard* s);
 
 #ifdef __cplusplus

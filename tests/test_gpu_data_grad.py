@@ -185,26 +185,62 @@ def test_device_data_gradients_match_mpmath_golden():
 
 
 @pytest.mark.parametrize("kernel,d", [("Exponential*Matern32+Matern32+RBF", 2), ("RBF+Matern52*Matern32+RBF", 3),
-                                      ("Matern52+RBF*RBF", 17), ("RBF+Matern32", 40)])
-def test_data_gradients_are_reproducible_for_every_component_count(kernel, d):
-    """Round-3 regression: a build of grad_x_kernel<4, 1> at 256 VGPRs + spilled SGPRs returned nondeterministic garbage
-    in dLML/dX (entries of 1e38, different on every call) while LML, dLML/dtheta and dLML/dy of the same evaluation were
-    right.  Fresh handles and repeated evaluations must return the same bits, and those must match the oracle."""
+                                      ("Matern52+RBF*RBF", 17), ("RBF+Matern32", 40), ("Matern32*RBF+Exponential+Matern52", 5)])
+def test_gradients_are_reproducible_for_every_component_count(kernel, d):
+    """Round-3 regression: a build of grad_x_kernel<4, 1> (fully unrolled, 86 KB of code, 256 VGPRs) returned
+    NONDETERMINISTIC garbage in dLML/dX -- entries of 1e13 that changed from call to call on identical inputs -- while LML,
+    dLML/dtheta and dLML/dy of the same evaluation were right.  Fresh handles and repeated evaluations must return the
+    same bits for every gradient entry point, and those must match the oracle."""
     MiGP, orc = _mods()
     N = 207
     X, y = orc.synth_problem(N, d, seed=17)
     kerns, ops = _split(kernel)
-    theta = orc.synth_theta(d, nkern=len(kerns), gv=1e-3)
-    theta[: len(kerns) * d] *= np.sqrt(d / 2.0)
-    _, _, gX_ref = orc.lml_grad_data(X, y, kerns, ops, theta)
-    first = None
-    for _ in range(3):
-        gp = MiGP(X, y, kernel)
+    rng = np.random.default_rng(d)
+    for rescale in (1.0, np.sqrt(d / 2.0)):
+        theta = orc.synth_theta(d, nkern=len(kerns), gv=1e-3)
+        theta[: len(kerns) * d] *= rescale
+        _, g_ref = orc.lml_grad(X, y, kerns, ops, theta)
+        _, _, gX_ref = orc.lml_grad_data(X, y, kerns, ops, theta)
+        Xn = rng.uniform(0.05, 0.95, (4, d))
+        dmu_ref, dvar_ref = orc.predict_grad(X, y, Xn, kerns, ops, theta)
+        first = None
         for _ in range(3):
-            _, _, _, gX = gp.lml_grad_data(theta)
-            if first is None:
-                first = gX.copy()
-            assert np.array_equal(gX, first)
-        gp.close()
-    scale = np.maximum(np.abs(gX_ref), 1e-3 * np.abs(gX_ref).max())
-    assert np.max(np.abs(first - gX_ref) / scale) <= (1e-5 if "Exponential" in kernel else 1e-7)
+            gp = MiGP(X, y, kernel)
+            for _ in range(3):
+                _, g, _, gX = gp.lml_grad_data(theta)
+                _, _, dmu, dvar = gp.predict_grad(theta, Xn)
+                if first is None:
+                    first = (g.copy(), gX.copy(), dmu.copy(), dvar.copy())
+                assert np.array_equal(g, first[0]) and np.array_equal(gX, first[1])
+                assert np.array_equal(dmu, first[2]) and np.array_equal(dvar, first[3])
+            gp.close()
+        tol = 1e-5 if "Exponential" in kernel else 1e-7
+        scale = np.maximum(np.abs(gX_ref), 1e-3 * np.abs(gX_ref).max())
+        assert np.max(np.abs(first[1] - gX_ref) / scale) <= tol
+        assert np.abs(first[0] - g_ref).max() <= tol * np.abs(g_ref).max()
+        assert np.abs(first[2] - dmu_ref).max() <= tol * np.abs(dmu_ref).max()
+        assert np.abs(first[3] - dvar_ref).max() <= tol * np.abs(dvar_ref).max()
+
+
+@pytest.mark.parametrize("N,d,kernel", [(300, 129, "RBF"), (260, 200, "Matern52"), (200, 300, "RBF+Matern32")])
+def test_data_and_predictive_gradients_beyond_128_input_dimensions(N, d, kernel):
+    """The reference loops over any number of input dimensions (gpmcmc.py:235-237, 282-307); round 2 refused d > 128 in
+    mi_gp_grad_x / mi_gp_predict_grad.  dLML/dX now runs one pass per window of 128 output dimensions, the predictive
+    gradient sizes its LDS by d."""
+    MiGP, orc = _mods()
+    X, y = orc.synth_problem(N, d, seed=d)
+    kerns, ops = _split(kernel)
+    theta = orc.synth_theta(d, nkern=len(kerns), gv=1e-3)
+    theta[: len(kerns) * d] *= np.sqrt(d / 2.0)  # length scales ~ sqrt(d): K is not numerically the identity
+    gp = MiGP(X, y, kernel)
+    val, g, gy, gX = gp.lml_grad_data(theta)
+    ref, gy_ref, gX_ref = orc.lml_grad_data(X, y, kerns, ops, theta)
+    assert abs(val - ref) <= 1e-9 * abs(ref)
+    assert np.abs(gy - gy_ref).max() <= 1e-8 * np.abs(gy_ref).max()
+    assert np.abs(gX - gX_ref).max() <= 1e-8 * np.abs(gX_ref).max()
+    Xn = np.random.default_rng(d).uniform(0.05, 0.95, (3, d))
+    mu, var, dmu, dvar = gp.predict_grad(theta, Xn)
+    dmu_o, dvar_o = orc.predict_grad(X, y, Xn, kerns, ops, theta)
+    assert np.abs(dmu - dmu_o).max() <= 1e-7 * np.abs(dmu_o).max()
+    assert np.abs(dvar - dvar_o).max() <= 1e-7 * np.abs(dvar_o).max()
+    gp.close()

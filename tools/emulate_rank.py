@@ -2,14 +2,11 @@
 the rank owns, updates and factors exactly its block-cyclic share of the panels; the panels the other ranks would
 broadcast are copied in from a complete factor computed beforehand on the same GPU.  Measured per step with HIP events:
 the owner chain (update of the next panel, its factorisation, staging) and the bulk update launch.  From the per-rank
-numbers a 1/2/4/8-GPU curve is PREDICTED (not measured):
-
-    T(W) = sum over steps j of  max( bulk_j(rank with most work),  chain_{j+1} + bytes_{j+1} / link_bandwidth )
-
-i.e. every step costs the slower of the trailing update and the serial path "owner updates + factors + stages the next
-panel, then the next owner must hold it" (xGMI point-to-point, ~153 GB/s per link; the broadcast's later hops overlap the
-following steps).  profiles/r03_sharded_model.json keeps the prediction so that the first hardware run can be checked
-against it; bench.py --sharded prints it next to the measurement.
+numbers a 1/2/4/8-GPU curve is PREDICTED (not measured) by replaying the per-step times on a timeline of `world` ranks
+(predict() below): a rank starts step j when panel j has arrived and its previous work is done; the owner of panel j + 1
+runs its chain ahead of (or beside) its bulk update; the panel arrives bytes / link bandwidth later (xGMI point-to-point,
+~153 GB/s per link; the broadcast's later hops overlap the following steps).  profiles/r03_sharded_model.json keeps the
+prediction so that the first hardware run can be checked against it; bench.py --sharded prints it next to the measurement.
 
     python tools/emulate_rank.py --world 8 --ranks 0,3,7 [--n 65536 --d 32 --kernel RBF --panel-tiles 4]
     python tools/emulate_rank.py --curve   # worlds 1,2,4,8, a few ranks each, writes the model file"""
@@ -79,22 +76,24 @@ def run_rank(X, y, kernel, theta, world, rank, pwt, source, reps=2, options=None
     return rec
 
 
-def predict(world, recs, N, pwt, link_gbps=LINK_GBPS):
-    """T(W) from the emulated ranks of one world size: per step the max over the emulated ranks' bulk times against the
-    owner's chain (taken from whichever emulated rank owned that panel; interpolated from its neighbours otherwise) plus
-    the link time of the panel to the next owner."""
+def predict(world, recs, N, pwt, serial, link_gbps=LINK_GBPS):
+    """Timeline of a `world`-rank evaluation from the emulated ranks' per-step times (a model, not a measurement).
+    Rank r at step j starts when panel j has arrived and its own previous work is done.  The owner of panel j + 1 runs
+    its chain (update + factor + stage) -- ahead of its bulk update (serial: option 3 = 1) or beside it on the side
+    stream (the measured bulk time then already contains the contention) -- and panel j + 1 arrives everywhere
+    bytes / link bandwidth later (xGMI point-to-point; the broadcast's later hops overlap the following steps).  Ranks that
+    were not emulated take the per-step times of the nearest emulated rank; chains of panels whose owner was not
+    emulated are interpolated over the panel index."""
     npan = recs[0]["npan"]
     pw = pwt * 128
     npad = (N + 127) // 128 * 128
-    bulk = np.zeros(npan)
+    by_rank = {r["rank"]: np.array(r["steps"]) for r in recs}
     chain = np.full(npan + 1, np.nan)
-    for r in recs:
-        st = np.array(r["steps"])
-        bulk = np.maximum(bulk, st[:npan, 3])
+    for r, st in by_rank.items():
         for j in range(npan):
-            c = st[j, 0] + st[j, 1] + st[j, 2]
+            c = st[j, 0] + st[j, 1] + st[j, 2] if serial else st[j, 0] + st[j, 1]  # beside a bulk update the staging waits for it
             if c > 0:
-                chain[j + 1] = c  # step j's side stream produced panel j + 1
+                chain[j + 1] = c  # step j produced panel j + 1
         if st[npan, 1] > 0:
             chain[0] = st[npan, 1] + st[npan, 2]
     idx = np.arange(npan + 1)
@@ -103,13 +102,28 @@ def predict(world, recs, N, pwt, link_gbps=LINK_GBPS):
     link = np.array([(npad + 128 - j * pw) * pw * 8 / (link_gbps * 1e9) * 1e3 for j in range(npan + 1)])  # ms
     if world == 1:
         link[:] = 0.0
-    serial = chain[0] + link[0]
+    emu = sorted(by_rank)
+    bulk = [by_rank[min(emu, key=lambda e: abs(e - r))][:npan, 3] for r in range(world)]
+    free = np.zeros(world)
+    avail = np.zeros(npan + 1)
+    free[0] = chain[0]
+    avail[0] = chain[0] + link[0]
     for j in range(npan):
-        nxt = (chain[j + 1] + link[j + 1]) if j + 1 < npan else 0.0
-        serial += max(bulk[j], nxt)
-    return {"world": world, "predicted_ms": float(serial), "sum_bulk_ms_slowest_rank": float(bulk.sum()),
+        o = (j + 1) % world if j + 1 < npan else -1
+        for r in range(world):
+            t = max(free[r], avail[j])
+            if r == o:
+                done = t + chain[j + 1]
+                avail[j + 1] = done + link[j + 1]
+                free[r] = (done if serial else t) + bulk[r][j]
+                if not serial:
+                    free[r] = max(free[r], done)
+            else:
+                free[r] = t + bulk[r][j]
+    return {"world": world, "chain": "on the main stream ahead of the bulk update" if serial else "on the side stream beside the bulk update",
+            "predicted_ms": float(free.max()), "sum_bulk_ms_slowest_rank": float(max(b.sum() for b in bulk)),
             "sum_chain_ms": float(chain[:npan].sum()), "sum_link_ms": float(link[:npan].sum()),
-            "link_GBps_assumed": link_gbps, "ranks_emulated": [r["rank"] for r in recs]}
+            "link_GBps_assumed": link_gbps, "ranks_emulated": emu}
 
 
 def main():
@@ -142,22 +156,26 @@ def main():
         pwt = args.panel_tiles or panel_tiles(ntc, world)
         if ranks is None:
             ranks = sorted({0, world // 2, world - 1})
-        recs = []
-        for r in ranks:
-            rec = run_rank(X, y, args.kernel, theta, world, r, pwt, (K, ld), options=opts)
-            recs.append(rec)
-            print(json.dumps({k: v for k, v in rec.items() if k != "steps"}), flush=True)
-        if len(ranks) == world:  # every rank emulated: their partial sums must add up to the single-GPU factor's
-            ld_sum, q_sum = sum(r["logdet_part"] for r in recs), sum(r["quad_part"] for r in recs)
-            assert abs(ld_sum - logdet) <= 1e-10 * abs(logdet) and abs(q_sum - quad) <= 1e-9 * abs(quad), (ld_sum, logdet, q_sum, quad)
-            print(f"partial sums of all {world} ranks reproduce the single-GPU log-det and quadratic form", flush=True)
-        pred = predict(world, recs, N, pwt)
-        pred["compute_ms_x_world_over_single"] = max(r["bulk_ms"] + r["update_ms"] + r["factor_ms"] for r in recs) * world / single_ms
-        print(json.dumps(pred), flush=True)
-        out["runs"] += [{k: v for k, v in r.items() if k != "steps"} for r in recs]
-        out["prediction"].append(pred)
-        os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
-        json.dump(out, open(args.out, "w"), indent=1)
+        for serial in ([0] if world == 1 else [1, 0]):
+            recs = []
+            for r in ranks:
+                rec = run_rank(X, y, args.kernel, theta, world, r, pwt, (K, ld), options={**opts, "3": serial})
+                rec["chain_on_main"] = serial
+                recs.append(rec)
+                print(json.dumps({k: v for k, v in rec.items() if k != "steps"}), flush=True)
+            if len(ranks) == world:  # every rank emulated: their partial sums must add up to the single-GPU factor's
+                ld_sum, q_sum = sum(r["logdet_part"] for r in recs), sum(r["quad_part"] for r in recs)
+                assert abs(ld_sum - logdet) <= 1e-10 * abs(logdet) and abs(q_sum - quad) <= 1e-9 * abs(quad), (ld_sum, logdet, q_sum, quad)
+                print(f"partial sums of all {world} ranks reproduce the single-GPU log-det and quadratic form", flush=True)
+            pred = predict(world, recs, N, pwt, bool(serial))
+            pred["panel_tiles"] = pwt
+            pred["speedup_vs_single_gpu_path"] = single_ms / pred["predicted_ms"]
+            pred["compute_ms_x_world_over_single"] = max(r["bulk_ms"] + r["update_ms"] + r["factor_ms"] for r in recs) * world / single_ms
+            print(json.dumps(pred), flush=True)
+            out["runs"] += [{k: v for k, v in r.items() if k != "steps"} for r in recs]
+            out["prediction"].append(pred)
+            os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
+            json.dump(out, open(args.out, "w"), indent=1)
 
 
 if __name__ == "__main__":

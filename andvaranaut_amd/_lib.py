@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmi_gp.so")
 
-MAX_KERN = 4
+MAX_KERN = 8
 KERNEL_IDS = {"RBF": 0, "Matern52": 1, "Matern32": 2, "Exponential": 3, "RatQuad": 4}
 OP_IDS = {"+": 0, "*": 1}
 

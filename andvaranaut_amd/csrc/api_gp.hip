@@ -94,7 +94,7 @@ static void release_handle(mi_gp_handle* h) {
 extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   if (!cfg || !out) { set_global_error("mi_gp_create: null argument"); return -1; }
   if (cfg->n <= 0 || cfg->d <= 0 || cfg->nkern <= 0 || cfg->nkern > MAX_KERN) {
-    set_global_error("mi_gp_create: n, d must be positive and 1 <= nkern <= 4");
+    set_global_error("mi_gp_create: n, d must be positive and 1 <= nkern <= 8");
     return -1;
   }
   for (int i = 0; i < cfg->nkern; ++i)

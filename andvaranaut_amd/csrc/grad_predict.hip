@@ -121,7 +121,8 @@ __global__ __launch_bounds__(256) void grad_contract_kernel(KernSpec spec, const
   __shared__ double red[256];
   const int tid = threadIdx.x;
   const int d = spec.d;
-  const int P = NK * d + 2 * NK + 2;
+  const int nk = NK > 4 ? spec.nkern : NK;  // NK = 8: one instantiation for 5..8 components, run-time count
+  const int P = nk * d + 2 * nk + 2;
   double* out = part + (long)blockIdx.x * P;
   int ti, tj;
   if (rect_tw > 0) {
@@ -145,8 +146,8 @@ __global__ __launch_bounds__(256) void grad_contract_kernel(KernSpec spec, const
   const int i0 = ti * GT, j0 = tj * GT;
   const int tx = tid & 15, ty = tid >> 4;
   const double* ls = theta;
-  const double* kv = theta + NK * d;
-  const double* al = kv + NK;
+  const double* kv = theta + nk * d;
+  const double* al = kv + nk;
 
   // weights: w_ab = (alpha_i alpha_j - W_ij) * (1 below the diagonal, 1/2 on it, 0 above / padding)
   double wgt[4][4];
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(256) void grad_contract_kernel(KernSpec spec, const
   // pass 1: per-component scaled squared distances r2[c] (direct form) -> value, derivative, fold
   double kval[NK][4][4], dkv[NK][4][4], dal[NK][4][4];
 #pragma unroll
-  for (int c = 0; c < NK; ++c) {
+  for (int c = 0; c < nk; ++c) {
     double r2[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -227,15 +228,15 @@ __global__ __launch_bounds__(256) void grad_contract_kernel(KernSpec spec, const
       double T = kval[0][a][b];
       pref[0] = 1.0;
 #pragma unroll
-      for (int c = 1; c < NK; ++c) {
+      for (int c = 1; c < nk; ++c) {
         pref[c] = (spec.op[c - 1] == 0) ? 1.0 : T;
         T = (spec.op[c - 1] == 0) ? T + kval[c][a][b] : T * kval[c][a][b];
       }
 #pragma unroll
-      for (int c = 0; c < NK; ++c) {
+      for (int c = 0; c < nk; ++c) {
         double coef = pref[c];
 #pragma unroll
-        for (int c2 = c + 1; c2 < NK; ++c2)
+        for (int c2 = c + 1; c2 < nk; ++c2)
           if (spec.op[c2 - 1] == 1) coef *= kval[c2][a][b];
         wc[c][a][b] = wgt[a][b] * coef;
       }
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(256) void grad_contract_kernel(KernSpec spec, const
 
   // kv, alpha, gv, jitter
 #pragma unroll
-  for (int c = 0; c < NK; ++c) {
+  for (int c = 0; c < nk; ++c) {
     double skv = 0.0, sal = 0.0;
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -264,8 +265,8 @@ __global__ __launch_bounds__(256) void grad_contract_kernel(KernSpec spec, const
     skv = block_sum(skv);
     sal = block_sum(sal);
     if (tid == 0) {
-      out[NK * d + c] = skv / kv[c];
-      out[NK * d + NK + c] = sal;
+      out[nk * d + c] = skv / kv[c];
+      out[nk * d + nk + c] = sal;
     }
   }
   {
@@ -277,13 +278,13 @@ __global__ __launch_bounds__(256) void grad_contract_kernel(KernSpec spec, const
         if (i0 + ty + 16 * a == j0 + tx + 16 * b) sd += wgt[a][b];  // already carries the 1/2
     sd = block_sum(sd);
     if (tid == 0) {
-      out[NK * d + 2 * NK] = sd;
-      out[NK * d + 2 * NK + 1] = sd;
+      out[nk * d + 2 * nk] = sd;
+      out[nk * d + 2 * nk + 1] = sd;
     }
   }
   // length scales: dK/dl_{c,m} = wc * kv dk/dr2 * (-2/l_m) * ((x_im - x_jm)/l_m)^2
 #pragma unroll
-  for (int c = 0; c < NK; ++c) {
+  for (int c = 0; c < nk; ++c) {
     for (int m0 = 0; m0 < d; m0 += GDCH) {
       const int dc = min(GDCH, d - m0);
       __syncthreads();
@@ -358,14 +359,15 @@ __global__ __launch_bounds__(256) void grad_x_kernel(KernSpec spec, const double
   __shared__ double ilc[NK * GXCH];     // 1 / l_cm of the pass-1 chunk being staged
   const int tid = threadIdx.x;
   const int d = spec.d;
+  const int nk = NK > 4 ? spec.nkern : NK;  // NK = 8: one instantiation for 5..8 components, run-time count
   const int dw = min(GX_MAXD, d - w0);  // this pass's output dimensions
   const int nt = (n + GT - 1) / GT;
   const int ib = blockIdx.x, i0 = ib * GT;
   const int tx = tid & 15, ty = tid >> 4;  // pass-1 micro-tile: rows ty+16a, cols tx+16b
   const int pr = tid & 63, pq = tid >> 6;  // pass-2: row pr, dimensions m = pq (mod 4)
-  const double* kv = theta + NK * d;
-  const double* al = kv + NK;
-  for (int e = tid; e < NK * dw; e += 256) ils[(e / dw) * GX_MAXD + e % dw] = 1.0 / theta[(e / dw) * d + w0 + e % dw];
+  const double* kv = theta + nk * d;
+  const double* al = kv + nk;
+  for (int e = tid; e < nk * dw; e += 256) ils[(e / dw) * GX_MAXD + e % dw] = 1.0 / theta[(e / dw) * d + w0 + e % dw];
   double acc[NCH][GXCH / 4];
 #pragma unroll
   for (int mc = 0; mc < NCH; ++mc)
@@ -391,7 +393,7 @@ __global__ __launch_bounds__(256) void grad_x_kernel(KernSpec spec, const double
     // pass 1: scaled squared distances per component
     double r2[NK][4][4];
 #pragma unroll
-    for (int c = 0; c < NK; ++c)
+    for (int c = 0; c < nk; ++c)
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -409,7 +411,7 @@ __global__ __launch_bounds__(256) void grad_x_kernel(KernSpec spec, const double
         Xi[r * GXLD + m] = vi;
         Xj[r * GXLD + m] = vj;
       }
-      if (tid < NK * GXCH) {
+      if (tid < nk * GXCH) {
         const int c = tid / GXCH, m = tid % GXCH;
         ilc[tid] = (m < dc) ? 1.0 / theta[c * d + m0 + m] : 0.0;
       }
@@ -421,7 +423,7 @@ __global__ __launch_bounds__(256) void grad_x_kernel(KernSpec spec, const double
 #pragma unroll
         for (int b = 0; b < 4; ++b) xj[b] = Xj[(tx + 16 * b) * GXLD + m];
 #pragma unroll
-        for (int c = 0; c < NK; ++c) {
+        for (int c = 0; c < nk; ++c) {
           const double il = ilc[c * GXCH + m];
 #pragma unroll
           for (int a = 0; a < 4; ++a)
@@ -438,7 +440,7 @@ __global__ __launch_bounds__(256) void grad_x_kernel(KernSpec spec, const double
     auto coef_elem = [&](int a, int b) {
       double kval[NK], dkv[NK];
 #pragma unroll
-      for (int c = 0; c < NK; ++c) {
+      for (int c = 0; c < nk; ++c) {
         double k, dk, da;
         base_kernel_val_der(spec.kid[c], r2[c][a][b], al[c], k, dk, da);
         kval[c] = kv[c] * k;
@@ -448,16 +450,16 @@ __global__ __launch_bounds__(256) void grad_x_kernel(KernSpec spec, const double
       double T = kval[0];
       pref[0] = 1.0;
 #pragma unroll
-      for (int c = 1; c < NK; ++c) {
+      for (int c = 1; c < nk; ++c) {
         pref[c] = (spec.op[c - 1] == 0) ? 1.0 : T;
         T = (spec.op[c - 1] == 0) ? T + kval[c] : T * kval[c];
       }
       const double w = Ct[(ty + 16 * a) * (GT + 1) + tx + 16 * b];
 #pragma unroll
-      for (int c = 0; c < NK; ++c) {
+      for (int c = 0; c < nk; ++c) {
         double coef = pref[c];
 #pragma unroll
-        for (int c2 = c + 1; c2 < NK; ++c2)
+        for (int c2 = c + 1; c2 < nk; ++c2)
           if (spec.op[c2 - 1] == 1) coef *= kval[c2];
         cf[c][a][b] = w * coef * dkv[c];
       }
@@ -482,7 +484,7 @@ __global__ __launch_bounds__(256) void grad_x_kernel(KernSpec spec, const double
     }
     // pass 2, one component at a time through the LDS tile
 #pragma unroll
-    for (int c = 0; c < NK; ++c) {
+    for (int c = 0; c < nk; ++c) {
       __syncthreads();  // everyone has read the weights (c == 0) / finished the previous component
 #pragma unroll
       for (int a = 0; a < 4; ++a)
@@ -604,7 +606,8 @@ hipError_t launch_grad_contract(const KernSpec& spec, const double* theta, const
     case 1: grad_contract_kernel<1><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, 0, 0, 0, 0); break;
     case 2: grad_contract_kernel<2><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, 0, 0, 0, 0); break;
     case 3: grad_contract_kernel<3><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, 0, 0, 0, 0); break;
-    default: grad_contract_kernel<4><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, 0, 0, 0, 0); break;
+    case 4: grad_contract_kernel<4><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, 0, 0, 0, 0); break;
+    default: grad_contract_kernel<8><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, 0, 0, 0, 0); break;
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
@@ -632,7 +635,8 @@ hipError_t launch_grad_contract_slab(const KernSpec& spec, const double* theta, 
     case 1: grad_contract_kernel<1><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, tw, tj0, row0, col0); break;
     case 2: grad_contract_kernel<2><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, tw, tj0, row0, col0); break;
     case 3: grad_contract_kernel<3><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, tw, tj0, row0, col0); break;
-    default: grad_contract_kernel<4><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, tw, tj0, row0, col0); break;
+    case 4: grad_contract_kernel<4><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, tw, tj0, row0, col0); break;
+    default: grad_contract_kernel<8><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, tw, tj0, row0, col0); break;
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
@@ -657,14 +661,15 @@ __global__ __launch_bounds__(256) void predict_grad_kernel(KernSpec spec, const 
   __shared__ double red[2][GXCH][4];
   const int tid = threadIdx.x;
   const int d = spec.d;
+  const int nk = NK > 4 ? spec.nkern : NK;  // NK = 8: one instantiation for 5..8 components, run-time count
   double* xs = pg_dyn;
   double* ils = pg_dyn + d;
   const int p = blockIdx.x;
-  const double* kv = theta + NK * d;
-  const double* al = kv + NK;
+  const double* kv = theta + nk * d;
+  const double* al = kv + nk;
   const double* w = wv + (long)p * ldwv;
   for (int e = tid; e < d; e += 256) xs[e] = xstar[(long)p * d + e];
-  for (int e = tid; e < NK * d; e += 256) ils[e] = 1.0 / theta[e];
+  for (int e = tid; e < nk * d; e += 256) ils[e] = 1.0 / theta[e];
   __syncthreads();
   for (int m0 = 0; m0 < d; m0 += GXCH) {
     const int dc = min(GXCH, d - m0);
@@ -675,7 +680,7 @@ __global__ __launch_bounds__(256) void predict_grad_kernel(KernSpec spec, const 
       const double* xi = X + (long)i * d;
       double kval[NK], dkv[NK];
 #pragma unroll
-      for (int c = 0; c < NK; ++c) {
+      for (int c = 0; c < nk; ++c) {
         double r2 = 0.0;
         for (int m = 0; m < d; ++m) {
           const double df = (xs[m] - xi[m]) * ils[c * d + m];
@@ -690,16 +695,16 @@ __global__ __launch_bounds__(256) void predict_grad_kernel(KernSpec spec, const 
       double T = kval[0];
       pref[0] = 1.0;
 #pragma unroll
-      for (int c = 1; c < NK; ++c) {
+      for (int c = 1; c < nk; ++c) {
         pref[c] = (spec.op[c - 1] == 0) ? 1.0 : T;
         T = (spec.op[c - 1] == 0) ? T + kval[c] : T * kval[c];
       }
       const double ai = alpha_v[i], wi = -2.0 * w[i];
 #pragma unroll
-      for (int c = 0; c < NK; ++c) {
+      for (int c = 0; c < nk; ++c) {
         double coef = pref[c];
 #pragma unroll
-        for (int c2 = c + 1; c2 < NK; ++c2)
+        for (int c2 = c + 1; c2 < nk; ++c2)
           if (spec.op[c2 - 1] == 1) coef *= kval[c2];
         const double g = coef * dkv[c];
 #pragma unroll
@@ -741,7 +746,8 @@ hipError_t launch_predict_grad(const KernSpec& spec, const double* theta, const 
     case 1: predict_grad_kernel<1><<<m, 256, lds, stream>>>(spec, theta, X, n, xstar, alpha, w, ldw, dmean, dvar); break;
     case 2: predict_grad_kernel<2><<<m, 256, lds, stream>>>(spec, theta, X, n, xstar, alpha, w, ldw, dmean, dvar); break;
     case 3: predict_grad_kernel<3><<<m, 256, lds, stream>>>(spec, theta, X, n, xstar, alpha, w, ldw, dmean, dvar); break;
-    default: predict_grad_kernel<4><<<m, 256, lds, stream>>>(spec, theta, X, n, xstar, alpha, w, ldw, dmean, dvar); break;
+    case 4: predict_grad_kernel<4><<<m, 256, lds, stream>>>(spec, theta, X, n, xstar, alpha, w, ldw, dmean, dvar); break;
+    default: predict_grad_kernel<8><<<m, 256, lds, stream>>>(spec, theta, X, n, xstar, alpha, w, ldw, dmean, dvar); break;
   }
   return hipGetLastError();
 }
@@ -787,7 +793,8 @@ hipError_t launch_grad_x(const KernSpec& spec, const double* theta, const double
     case 1: GX_LAUNCH(1); break;
     case 2: GX_LAUNCH(2); break;
     case 3: GX_LAUNCH(3); break;
-    default: GX_LAUNCH(4); break;
+    case 4: GX_LAUNCH(4); break;
+    default: GX_LAUNCH(8); break;
   }
 #undef GX_LAUNCH
   hipError_t e = hipGetLastError();

@@ -63,7 +63,8 @@ hipError_t launch_trsm_strip128_batched(const double* minv, double* B, long ldb,
 
 // ---------------------------------------------------------------- assemble.hip
 enum { KID_RBF = 0, KID_MATERN52 = 1, KID_MATERN32 = 2, KID_EXPONENTIAL = 3, KID_RATQUAD = 4 };
-constexpr int MAX_KERN = 4;
+constexpr int MAX_KERN = 8;  // the gradient kernels are specialised for 1..4 components and take 5..8 through one
+                             // instantiation with a run-time component count (arrays in scratch: slower, same arithmetic)
 struct KernSpec {
   int nkern;
   int d;

@@ -27,7 +27,7 @@ extern "C" {
 
 enum { MI_GP_RBF = 0, MI_GP_MATERN52 = 1, MI_GP_MATERN32 = 2, MI_GP_EXPONENTIAL = 3, MI_GP_RATQUAD = 4 };
 enum { MI_GP_OP_ADD = 0, MI_GP_OP_MUL = 1 };
-#define MI_GP_MAX_KERN 4
+#define MI_GP_MAX_KERN 8
 
 typedef struct mi_gp_handle mi_gp_handle;
 

@@ -149,7 +149,7 @@ def test_config4_shape_fits_one_gpu():
 
 
 def test_four_component_kernel_and_many_dims():
-    """MI_GP_MAX_KERN components and d > 64 (three LDS chunks of the input dimension)."""
+    """Four components (the specialised gradient kernels' limit) and d > 64 (three LDS chunks of the input dimension)."""
     MiGP, orc = _mods()
     N, d = 400, 70
     X, y = orc.synth_problem(N, d, seed=5)
@@ -168,6 +168,42 @@ def test_four_component_kernel_and_many_dims():
     rmu, rvar = orc.predict(X, y, Xn, kerns, ops, theta)
     assert np.allclose(mu, rmu, rtol=1e-9, atol=1e-9) and np.allclose(var, rvar, rtol=1e-8, atol=1e-11)
     gp.close()
+
+
+@pytest.mark.parametrize("kernel", ["RBF+Matern52*Matern32+RBF+Matern52", "Matern32*RBF+Matern52+RBF*Matern32+Matern52",
+                                    "RBF+Matern52+Matern32+RBF*Matern52+Matern32+RBF+Matern52"])
+def test_five_to_eight_component_kernels(kernel):
+    """The reference folds any number of components (gpmcmc.py:282-307); MI_GP_MAX_KERN is 8 since round 3 (the gradient
+    kernels take 5..8 components through one instantiation with a run-time count).  Every entry point against the oracle."""
+    MiGP, orc = _mods()
+    N, d = 333, 3
+    X, y = orc.synth_problem(N, d, seed=9)
+    kerns, ops = _split(kernel)
+    nk = len(kerns)
+    assert 5 <= nk <= 8
+    theta = orc.synth_theta(d, nkern=nk, gv=1e-3)
+    theta[: nk * d] *= np.random.default_rng(nk).uniform(0.8, 1.5, nk * d)
+    theta[nk * d: nk * d + nk] = np.random.default_rng(nk + 1).uniform(0.6, 1.4, nk)
+    gp = MiGP(X, y, kernel)
+    val, g, gy, gX = gp.lml_grad_data(theta)
+    ref, gref = orc.lml_grad(X, y, kerns, ops, theta)
+    _, gy_ref, gX_ref = orc.lml_grad_data(X, y, kerns, ops, theta)
+    assert abs(val - ref) <= 1e-10 * abs(ref), (val, ref)
+    assert np.abs(g - gref).max() <= 1e-8 * np.abs(gref).max()
+    assert np.abs(gy - gy_ref).max() <= 1e-8 * np.abs(gy_ref).max()
+    assert np.abs(gX - gX_ref).max() <= 1e-8 * np.abs(gX_ref).max()
+    Xn = np.random.default_rng(1).random((7, d))
+    mu, var, dmu, dvar = gp.predict_grad(theta, Xn)
+    rmu, rvar = orc.predict(X, y, Xn, kerns, ops, theta)
+    dmu_o, dvar_o = orc.predict_grad(X, y, Xn, kerns, ops, theta)
+    assert np.allclose(mu, rmu, rtol=1e-9, atol=1e-9) and np.allclose(var, rvar, rtol=1e-8, atol=1e-11)
+    assert np.abs(dmu - dmu_o).max() <= 1e-7 * np.abs(dmu_o).max()
+    assert np.abs(dvar - dvar_o).max() <= 1e-7 * np.abs(dvar_o).max()
+    v2, g2, _, gX2 = gp.lml_grad_data(theta)
+    assert v2 == val and np.array_equal(g2, g) and np.array_equal(gX2, gX)
+    gp.close()
+    with pytest.raises(Exception):
+        MiGP(X, y, "+".join(["RBF"] * 9))
 
 
 def test_handles_can_be_created_and_destroyed_repeatedly():

@@ -38,6 +38,9 @@ out["config5_nuts"] = {"N": N, "d": d, "draws": 30, "tune": 30, "leapfrogs": r["
                        "grad_evals_per_s": r["n_leapfrog"] / dt, "mean_tree_depth": r["mean_tree_depth"], "diverging": r["diverging"],
                        "lp_mean": float(np.mean(r["lp"]))}
 print(json.dumps(out["config5_nuts"]), flush=True)
+if out["config5_nuts"]["diverging"]:
+    print(f"WARNING: {out['config5_nuts']['diverging']} divergent transitions: this run is too short for the step size to adapt "
+          "(tools/run_config5_nuts.py is the reference-length run)", flush=True)
 # the same with three chains side by side on this GPU (what GPMCMC.fit(method='mcmc_*') does with more chains than GPUs)
 import threading
 others = [MiGP(X, y, "RBF") for _ in range(2)]
@@ -55,4 +58,6 @@ nl = sum(r_["n_leapfrog"] for r_ in res)
 out["config5_nuts_three_chains_one_gpu"] = {"chains": 3, "leapfrogs": nl, "seconds": dt3, "grad_evals_per_s": nl / dt3,
                                              "diverging": [r_["diverging"] for r_ in res]}
 print(json.dumps(out["config5_nuts_three_chains_one_gpu"]), flush=True)
+if any(out["config5_nuts_three_chains_one_gpu"]["diverging"]):
+    print(f"WARNING: divergent transitions {out['config5_nuts_three_chains_one_gpu']['diverging']} in the three-chain run", flush=True)
 json.dump(out, open("gpurun_out/configs_3_5.json", "w"), indent=1)

@@ -102,6 +102,7 @@ def load():
     lib.mi_gp_chol_panel.argtypes = [vp, cl, ci, ci, vp, vp, ci, vp]
     lib.mi_gp_lml_partial.argtypes = [vp, cl, vp, ci, vp, vp]
     lib.mi_gp_gemm_f64.argtypes = [ci, ci, ci, ci, ci, cd, vp, cl, vp, cl, cd, vp, cl, ci, ci, ci, cl, cl, cl, vp]
+    lib.mi_gp_gemm_f64_tuned.argtypes = [ci, ci, ci, ci, ci, cd, vp, cl, vp, cl, cd, vp, cl, ci, ci, ci, ci, ci, ci, vp]
     lib.mi_gp_trsm_block.argtypes = [vp, cl, vp, ci, ci, vp, cl, ci, vp]
     lib.mi_gp_trmv_upper.argtypes = [vp, cl, vp, ci, vp, vp]
     lib.mi_gp_grad_contract_block_scratch.argtypes = [ci, ci, ci, ci]
@@ -147,6 +148,7 @@ EXPORTS = [
     "mi_gp_set_profiling",
     "mi_gp_timers",
     "mi_gp_gemm_f64",
+    "mi_gp_gemm_f64_tuned",
     "mi_gp_assemble_block",
     "mi_gp_chol_panel",
     "mi_gp_lml_partial",

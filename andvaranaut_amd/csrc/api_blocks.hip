@@ -48,6 +48,27 @@ extern "C" int mi_gp_gemm_f64(int transa, int transb, int m, int n, int k, doubl
   return 0;
 }
 
+// The same product with the launcher's per-call knobs exposed (a handle carries them as options 7 / 9 / 14): which tile
+// size serves the launch, whether a 128x128-tile launch finishes its last partial round on 64x64 tiles, and the band
+// height of the trapezoid tile order.  For A/B measurements of single launches (tools/bench_gemm_shapes.py) and tests.
+extern "C" int mi_gp_gemm_f64_tuned(int transa, int transb, int m, int n, int k, double alpha, const double* A, long lda,
+                                    const double* B, long ldb, double beta, double* C, long ldc, int tri, int kmode,
+                                    int small_below, int tail_small, int band, int one_per_cu, void* stream) {
+  if (m % 128 || n % 128 || k % 32 || m <= 0 || n <= 0 || k < 0 || (lda & 1) || (ldb & 1)) {
+    snprintf(g_err, sizeof(g_err), "mi_gp_gemm_f64_tuned: m,n must be multiples of 128, k of 32, lda/ldb even");
+    return -1;
+  }
+  if (int r = ensure_init()) return r;
+  GemmParams p;
+  p.A = A; p.B = B; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.strideA = p.strideB = p.strideC = 0;
+  p.mt = m / 128; p.nt = n / 128; p.k = k; p.tri = tri; p.kmode = kmode; p.alpha = alpha; p.beta = beta;
+  p.small_below = small_below; p.tail_small = tail_small ? 1 : 0; p.band = band; p.one_per_cu = one_per_cu ? 1 : 0;
+  hipError_t e = launch_gemm_f64(p, transa ? 1 : 0, transb ? 0 : 1, 1, (hipStream_t)stream);
+  if (e != hipSuccess) return fail(e, "launch_gemm_f64");
+  return 0;
+}
+
 // ---------------------------------------------------------------- distributed-matrix building blocks
 static KernSpec make_spec(int d, int nkern, const int* kernel_ids, const int* ops) {
   KernSpec s;

@@ -151,6 +151,13 @@ int mi_gp_gemm_f64(int transa, int transb, int m, int n, int k, double alpha, co
                    const double* B_dev, long ldb, double beta, double* C_dev, long ldc, int tri, int kmode,
                    int batch, long strideA, long strideB, long strideC, void* hip_stream);
 
+/* The same product (batch 1) with the launcher's knobs per call: launches with fewer than small_below 128x128 tiles run on
+ * 64x64 tiles (handle option 7), tail_small (option 9), band height of the trapezoid tile order (option 14), one workgroup
+ * per CU (option 8's effect).  For A/B measurements of single launches and the GEMM tests. */
+int mi_gp_gemm_f64_tuned(int transa, int transb, int m, int n, int k, double alpha, const double* A_dev, long lda,
+                         const double* B_dev, long ldb, double beta, double* C_dev, long ldc, int tri, int kmode,
+                         int small_below, int tail_small, int band, int one_per_cu, void* hip_stream);
+
 /* K(Xrows, Xcols) for one rectangular block of a (distributed) covariance: rows row0.. and columns
  * col0.. of the global matrix; noise + jitter go on the global diagonal, identity in the padding
  * (rows >= nrows / columns >= ncols of the padded block).  Same kernel as the single-GPU assembly

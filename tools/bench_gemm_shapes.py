@@ -7,6 +7,9 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from andvaranaut_amd import _lib
 lib = _lib.load()
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+SMALL_BELOW = int(os.environ.get("SMALL_BELOW", "1024"))  # launches with fewer 128x128 tiles run on 64x64 tiles
+TAIL = int(os.environ.get("TAIL", "1"))
+BAND = int(os.environ.get("BAND", "8"))
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 ld = 16384 + 16
@@ -18,7 +21,8 @@ out = []
 for (m, n, k) in shapes:
     P, C = A[:m, 2048:2048 + k], A[:m, 4096:4096 + n]
     def run():
-        r = lib.mi_gp_gemm_f64(0, 1, m, n, k, -1.0, P.data_ptr(), ld, P.data_ptr(), ld, 1.0, C.data_ptr(), ld, 1, 0, 1, 0, 0, 0, None)
+        r = lib.mi_gp_gemm_f64_tuned(0, 1, m, n, k, -1.0, P.data_ptr(), ld, P.data_ptr(), ld, 1.0, C.data_ptr(), ld, 1, 0,
+                                     SMALL_BELOW, TAIL, BAND, 0, None)
         assert r == 0
     for _ in range(3):
         run()

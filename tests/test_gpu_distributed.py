@@ -116,6 +116,15 @@ for (N, d, kernel, pwt) in [(1500, 4, "RBF", None), (2100, 5, "Matern52", None),
     scale = np.maximum(np.abs(gref), 1e-3 * np.max(np.abs(gref)))
     assert v2 == val and np.max(np.abs(g - gref) / scale) <= 1e-7, (rank, N, g, gref)
     out[(N, pwt)] = [val] + g.tolist()
+    # the owner chain beside the bulk update on the side stream (one-rank default) instead of ahead of it on the main
+    # stream (several-rank default): same arithmetic per panel up to the tile size of one update -> agreement to rounding
+    gp.set_option(3, 0)
+    v3 = gp.lml(theta)
+    assert abs(v3 - val) <= 1e-11 * abs(val), (rank, N, v3, val)
+    v4, g4 = gp.lml_grad(theta)
+    assert v4 == v3 and np.max(np.abs(g4 - g) / scale) <= 1e-9, (rank, N)
+    gp.set_option(3, 1)
+    assert gp.lml(theta) == val  # and back: bit-identical to the first evaluation
 vals = parallel.gather_objects(out)
 assert all(v == vals[0] for v in vals), vals  # every rank holds the same all-reduced LML
 if rank == 0:

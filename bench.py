@@ -226,6 +226,21 @@ def sharded_record(args, rank, world, dev, N, d, kernel, steps, warmup, grad=Fal
     gp.close()
     del gp
     torch.cuda.empty_cache()
+    # parity of the sharded result on whatever hardware this runs on: rank 0 evaluates the same covariance once on the
+    # single-GPU path (34 GB at N = 65536; a second or two) and the record carries the relative difference
+    if not grad and rank == 0:
+        try:
+            from andvaranaut_amd import MiGP
+
+            one = MiGP(X, y, kernel, device=dev.index, need_grad=False)
+            ref = one.lml(thetas[warmup + steps - 1])
+            one.close()
+            del one
+            torch.cuda.empty_cache()
+            rec["single_gpu_lml"] = float(ref)
+            rec["rel_diff_vs_single_gpu_path"] = abs(float(vals[-1]) - float(ref)) / abs(float(ref))
+        except Exception as e:  # noqa: BLE001 - e.g. not enough free HBM next to other handles: the timing stands on its own
+            rec["single_gpu_check"] = f"skipped: {type(e).__name__}: {e}"
     # the one-GPU rank emulation's prediction for this world size (tools/emulate_rank.py --curve), for the first hardware
     # run to be checked against: a model (measured per-rank compute and owner chain + bytes / link bandwidth), not a result
     mfile = os.path.join(ROOT, "profiles", "r03_sharded_model.json")

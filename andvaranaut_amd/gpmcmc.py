@@ -494,9 +494,19 @@ class GPMCMC(ConsumersMixin):
             return max(1, min(3, nchain, base + int(0.8 * free // need)))
 
         # a lane = one host thread + one handle; the chains of a device are dealt round-robin to its lanes
-        def run_lane(dev, cs, h_existing):
+        def run_lane(dev, cs, h_existing, shared):
             try:
                 h = h_existing or MiGP(xin, yin, self.kernel, device=dev)
+                # Lanes that SHARE a GPU give up the look-ahead stream between 36 and 64 tile columns: the other lanes fill
+                # the idle CUs anyway and a hand-off between two streams costs ~10 us (three handles, LML + gradient: N = 6144
+                # 176 -> 202 evaluations/s, N = 8192 94 -> 97; from 72 tile columns on there is nothing in it).  The
+                # super-panel width is pinned to the one the two-stream driver would pick, so the arithmetic -- and every
+                # draw -- is bit-identical to the default schedule.
+                ntc = (len(yin) + 127) // 128
+                pinned = shared and 36 <= ntc <= 64
+                if pinned:
+                    h.set_option(2, 4)
+                    h.set_option(0, 0)
                 try:
                     lik = self._warp_likelihood(h, x, y, xin, iwgp, cwgp) if (iwgp or cwgp) else None
                     f = lambda q: model.logp_dlogp(q, h.lml_grad, likelihood=lik)  # noqa: E731
@@ -507,6 +517,9 @@ class GPMCMC(ConsumersMixin):
                 finally:
                     if h_existing is None:
                         h.close()
+                    elif pinned:
+                        h.set_option(2, 0)
+                        h.set_option(0, 1)
             except Exception as e:  # noqa: BLE001 - reported by the caller's thread
                 errors.append(e)
 
@@ -516,7 +529,7 @@ class GPMCMC(ConsumersMixin):
             for lane in range(k):
                 mine = cs[lane::k]
                 if mine:
-                    threads.append(threading.Thread(target=run_lane, args=(dev, mine, gp if (dev == self.device and lane == 0) else None)))
+                    threads.append(threading.Thread(target=run_lane, args=(dev, mine, gp if (dev == self.device and lane == 0) else None, k > 1)))
         for t in threads:
             t.start()
         for t in threads:

@@ -250,6 +250,26 @@ def test_tuning_options_do_not_change_results():
     gp.close()
 
 
+def test_shared_lane_schedule_is_bit_identical_to_the_default():
+    """GPMCMC.fit runs chains that share a GPU on single-stream handles between 36 and 64 tile columns, with the
+    super-panel width the two-stream default would pick pinned (options 2 = 4, 0 = 0): same arithmetic, same bits --
+    every draw of a chain equals the default schedule's."""
+    MiGP, orc = _mods()
+    X, y = orc.synth_problem(5000, 5, seed=4)  # 40 tile columns
+    theta = orc.synth_theta(5)
+    gp = MiGP(X, y, "Matern52")
+    v0, g0 = gp.lml_grad(theta)
+    gp.set_option(2, 4)
+    gp.set_option(0, 0)
+    v1, g1 = gp.lml_grad(theta)
+    assert v1 == v0 and np.array_equal(g1, g0)
+    assert gp.lml(theta) == v0
+    gp.set_option(2, 0)
+    gp.set_option(0, 1)
+    assert gp.lml(theta) == v0
+    gp.close()
+
+
 def test_options_are_per_handle():
     """Two handles with different launcher options in one process (fit(method='mcmc_*') drives one handle per GPU from
     one thread each): neither sees the other's knobs, both return the same bits."""

@@ -13,6 +13,8 @@ for T in [int(t) for t in os.environ.get("HANDLES", "1,2,3,4").split(",")]:
     for t in range(T):
         X, y = synth_problem(N, d, seed=t)
         gps.append(MiGP(X, y, "RBF", need_grad=grad))
+        for kv in filter(None, os.environ.get("MIGP_OPTS", "").split(",")):  # e.g. MIGP_OPTS=0=0: single-stream handles
+            gps[-1].set_option(int(kv.split("=")[0]), int(kv.split("=")[1]))
     def work(gp):
         f = (lambda t_: gp.lml_grad(t_)[0]) if grad else gp.lml
         for i in range(reps):

@@ -39,10 +39,16 @@ class MiGP:
         if not torch.cuda.is_available():
             raise RuntimeError("MiGP needs a ROCm GPU: the GP hot path has no CPU implementation")
         self.lib = _lib.load()
+        self._options = {}  # what set_option was called with (get_option)
         X = np.ascontiguousarray(X, dtype=np.float64)
         y = np.ascontiguousarray(np.asarray(y, dtype=np.float64).reshape(-1))
         if X.ndim != 2 or X.shape[0] != y.shape[0]:
             raise ValueError("X must be (n,d) and y (n,)")
+        if not (np.isfinite(X).all() and np.isfinite(y).all()):
+            # the device exp clamps its argument (migp_math.h): a NaN input would come out as a finite covariance entry,
+            # where the reference's PyTensor graph propagates NaN and the "posdef" check rejects the point
+            raise ValueError("X and y must be finite")
+        self._bad_data = False
         self.n, self.d = X.shape
         self.kerns, self.ops = parse_kernel(kernel)
         self.nkern = len(self.kerns)
@@ -97,6 +103,9 @@ class MiGP:
         theta, tp = self._theta(theta)
         out = ctypes.c_double()
         self._factored_ok = False
+        if self._bad_data:  # non-finite warped data: what PyMC turns into logp = -inf (update_data)
+            self.info = 1
+            return -np.inf
         self.info = self._check(self.lib.mi_gp_lml(self.h, tp, ctypes.byref(out)), "mi_gp_lml")
         return out.value
 
@@ -114,6 +123,9 @@ class MiGP:
         grad = np.zeros(self.ntheta)
         gp_ = grad.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
         self._factored_ok = False
+        if self._bad_data:
+            self.info = 1
+            return -np.inf, grad
         self.info = self._check(self.lib.mi_gp_lml_grad(self.h, tp, ctypes.byref(out), gp_), "mi_gp_lml_grad")
         return out.value, grad
 
@@ -137,8 +149,15 @@ class MiGP:
 
     def update_data(self, X=None, y=None):
         """Overwrite the resident inputs / outputs in place (same shapes): warped data change at every
-        posterior evaluation while the buffers, the handle and its streams stay."""
+        posterior evaluation while the buffers, the handle and its streams stay.  Non-finite data (an overflowing warp)
+        are not uploaded: until the next finite update lml / lml_grad return -inf like a non-positive-definite covariance
+        (the reference's graph would produce NaN and PyMC's checks reject the point)."""
         self._factored_ok = False
+        bad = (X is not None and not np.isfinite(np.asarray(X, dtype=np.float64)).all()) or \
+              (y is not None and not np.isfinite(np.asarray(y, dtype=np.float64)).all())
+        self._bad_data = bool(bad)
+        if bad:
+            return
         with torch.cuda.device(self.dev):
             if X is not None:
                 X = np.ascontiguousarray(X, dtype=np.float64)
@@ -260,6 +279,11 @@ class MiGP:
         """Per-handle tuning knobs (include/mi_gp.h: 0 look-ahead, 2 super-panel width, 7 small-tile threshold,
         8 one-workgroup-per-CU bulk updates, 14 tile order); unknown ids raise."""
         self._check(self.lib.mi_gp_set_option(self.h, int(what), int(value)), "mi_gp_set_option")
+        self._options[int(what)] = int(value)
+
+    def get_option(self, what, default=None):
+        """Last value set through set_option on this handle (the library's own defaults are not mirrored: `default`)."""
+        return self._options.get(int(what), default)
 
     def set_profiling(self, level):
         self.lib.mi_gp_set_profiling(self.h, int(level))

@@ -8,7 +8,10 @@ namespace migp {
 // exp(x) for x <= 0 (any magnitude, -inf included): Cody-Waite reduction by ln 2 in two pieces, degree-13 Taylor polynomial
 // on |r| <= ln2 / 2 (remainder 4e-18 relative), ldexp.  Max error 1.0 ulp against libm over [-745, 0]; arguments below
 // -746 (exp underflows to 0 from -745.13 on) are clamped there, so -inf -- r2 = inf from an underflowing length scale --
-// gives 0 like libm, not NaN (the unclamped reduction computed inf - inf).
+// gives 0 like libm, not NaN (the unclamped reduction computed inf - inf).  That holds for the RBF family only: the Matern /
+// Exponential argument goes through sqrt_pos first, and sqrt_pos(inf) is NaN.  fmax also turns a NaN argument into -746:
+// NaN does NOT propagate through this function, which is why the host rejects non-finite theta (factor_internal) and
+// non-finite X / y (MiGP.__init__, MiGP.update_data) before anything reaches the device.
 __device__ __forceinline__ double exp_nonpos(double x) {
   x = __builtin_fmax(x, -746.0);
   const double k = __builtin_rint(x * 1.4426950408889634);

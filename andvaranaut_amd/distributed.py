@@ -209,6 +209,13 @@ class DistGP:
                         work = self._exchange(jn)
                 if _keep:
                     self._keep_panel(j, self.P[j % 2])
+                    if chain_stream is not main:
+                        # the copy above reads P[j % 2] on the main stream AFTER this step's ready / bulk events were
+                        # recorded, and the side stream's next staging (step j + 1, panel j + 2) overwrites that very
+                        # buffer: order it behind the copy (nothing else did; a write-after-read race)
+                        kept = torch.cuda.Event()
+                        kept.record(main)
+                        self.side.wait_event(kept)
             self._scheck(lib.mi_gp_shard_finish(sh, ms, ss), "mi_gp_shard_finish")
             # local pieces of sum log L_ii and |beta|^2, then one small all-reduce
             acc = self.out[1:3].clone()

@@ -505,6 +505,9 @@ class GPMCMC(ConsumersMixin):
                 ntc = (len(yin) + 127) // 128
                 pinned = shared and 36 <= ntc <= 64
                 if pinned:
+                    # the caller's own handle gets its previous settings back afterwards (library defaults: look-ahead by
+                    # size = 1, super-panel width by size = 0)
+                    before = (h.get_option(2, 0), h.get_option(0, 1))
                     h.set_option(2, 4)
                     h.set_option(0, 0)
                 try:
@@ -518,8 +521,8 @@ class GPMCMC(ConsumersMixin):
                     if h_existing is None:
                         h.close()
                     elif pinned:
-                        h.set_option(2, 0)
-                        h.set_option(0, 1)
+                        h.set_option(2, before[0])
+                        h.set_option(0, before[1])
             except Exception as e:  # noqa: BLE001 - reported by the caller's thread
                 errors.append(e)
 

@@ -245,7 +245,11 @@ int mi_gp_shard_finish(mi_gp_shard* s, void* main_stream, void* side_stream);
  *          3 the owner's chain (update + factor + stage of the next panel) runs on main_stream AHEAD of its bulk update
  *            instead of beside it on side_stream (default: 1 when world > 1 -- every other rank waits for that chain, and
  *            alone on the chip it is 2-3x shorter than next to a bulk update; 0 on one rank).  Either way side_stream is
- *            ordered behind the staging when the call returns: the caller broadcasts the panel under side_stream. */
+ *            ordered behind the staging when the call returns: the caller broadcasts the panel under side_stream.
+ * Reproducibility: the sharded factorisation is bit-reproducible for a FIXED world size, panel width and option set.
+ * Options 2 and 3 and the world size change which launches update a panel (the early next-panel update goes through the
+ * ordinary launcher and may run on 64x64 tiles where the panel-list launch uses 128x128), i.e. they regroup sums: results
+ * then agree to rounding (1e-11 relative on the LML in the tests), not bit for bit. */
 int mi_gp_shard_set_option(mi_gp_shard* s, int what, int value);
 /* per-step phase times of the last evaluation (option 1; call after synchronising): out[4 * j + 0..3] =
  * update_ms, factor_ms, stage_ms, bulk_ms of step j (0 where the step had no such phase; factor of panel 0 is in

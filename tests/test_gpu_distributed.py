@@ -197,3 +197,34 @@ def test_emulated_ranks_partition_the_factorisation(world, pwt, N):
         gp.close()
     assert abs(ld_sum - logdet) <= 1e-10 * abs(logdet), (ld_sum, logdet)
     assert abs(q_sum - quad) <= 1e-9 * abs(quad), (q_sum, quad)
+
+
+@pytest.mark.parametrize("chain_on_main", [0, 1])
+def test_kept_factor_of_the_sharded_gradient_equals_the_single_gpu_factor(chain_on_main):
+    """with the owner's chain on the SIDE stream the copy that keeps panel j for the gradient raced with
+    the staging of panel j + 2 into the same buffer.  The kept factor (lower triangle of Lf, the leaf inverses through
+    the gradient, beta) must equal the single-GPU factor of the same covariance, in both stream placements, over many
+    narrow panels and repeated evaluations."""
+    import torch
+
+    from andvaranaut_amd import MiGP
+    from andvaranaut_amd.distributed import DistGP
+    from oracle import gp_oracle as orc
+
+    N, d = 3000, 4
+    X, y = orc.synth_problem(N, d, seed=21)
+    theta = orc.synth_theta(d, nkern=1)
+    one = MiGP(X, y, "Matern52")
+    v1, g1 = one.lml_grad(theta)
+    torch.cuda.synchronize()
+    L1 = torch.tril(one.K_t[:N, :N]).cpu().numpy()   # mi_gp_lml_grad leaves L (marginal form) in K_dev
+    gp = DistGP(X, y, "Matern52", panel_width_tiles=2)   # 12 panels: many buffer reuses
+    gp.set_option(3, chain_on_main)
+    for _ in range(3):
+        val, g = gp.lml_grad(theta)
+        torch.cuda.synchronize()
+        L = torch.tril(gp.Lf[:N, :N]).cpu().numpy()
+        assert np.abs(L - L1).max() <= 1e-11 * np.abs(L1).max()
+        assert abs(val - v1) <= 1e-11 * abs(v1)
+        assert _grad_close(g, g1, rtol=1e-8), (g, g1)
+    one.close()

@@ -31,6 +31,11 @@ struct mi_gp_handle {
   int w_thr[3];     // trailing sizes (tile columns) above which the super-panel is 16 / 8 / 4 tiles wide
   int small_below;  // GEMM launches with fewer 128x128 tiles than this run on 64x64 tiles
   int band_rows;    // band height of the band-column-major tile order of uniform-k trapezoid launches
+  int split_tiles;  // option 18: tiles of a bulk update that run one workgroup per CU beside the chain; the rest two per CU (0: no split)
+  int split_min_rest;  // option 19: ... only when at least this many tiles remain for the second part
+  int single_below;    // option 21: trailing tile columns at or below which a two-stream factorisation continues on one stream (0: never)
+  int merge_min_tiles; // option 20: trailing sizes (tile columns) from which the next super-panel's update rides at the head of the
+                       // trailing update's enumeration instead of in launches of its own (0: never)
   mi_gp_buffers buf;
   bool have_data;
   // handle-owned small scratch
@@ -136,6 +141,10 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   h->chain_prio = 1;  // N = 8192: 6.06 -> 5.94 ms, N = 16384: 28.11 -> 27.74 ms (interleaved A/B)
   h->small_below = GemmParams().small_below;
   h->band_rows = GemmParams().band;
+  h->split_tiles = 2048;
+  h->split_min_rest = 1024;
+  h->merge_min_tiles = 72;
+  h->single_below = 16;
   // round-2 A/B (tools/dev_ab_opts.py, interleaved in one process): bulk updates at one workgroup per CU whenever the
   // panel chain runs beside them (N = 16384: 29.99 -> 28.97 ms) and 8-tile super-panels at every size (N = 2048 1.045 ->
   // 1.017 ms, 4096 2.470 -> 2.388, 8192 6.417 -> 6.348, 16384 28.59 -> 28.39 against the 8 / 4 split of round 1)
@@ -194,6 +203,10 @@ extern "C" int mi_gp_set_option(mi_gp_handle* h, int what, int value) {
   else if (what == 8) h->lowocc_thr = value;
   else if (what == 14) h->band_rows = value;
   else if (what == 16) h->chain_prio = value;
+  else if (what == 18) h->split_tiles = value;
+  else if (what == 19) h->split_min_rest = value;
+  else if (what == 20) h->merge_min_tiles = value;
+  else if (what == 21) h->single_below = value;
   else if (what == 9) h->tail_small = value ? 1 : 0;
   else {
     snprintf(h->err, sizeof(h->err), "mi_gp_set_option: unknown option %d", what);
@@ -212,11 +225,17 @@ extern "C" int mi_gp_set_profiling(mi_gp_handle* h, int level) {
 static hipError_t prof_gemm(mi_gp_handle* h, const GemmParams& p, int ak, int bk, int batch, double flops,
                             hipStream_t st) {
   if (h->prof_level >= 2) {
-    // one event pair per kernel launch: a split product (gemm_tail_tiles) is two launches, its flops divided by tiles
+    // one event pair per kernel launch: a split product (gemm_tail_tiles) is two launches, its flops divided by tiles;
+    // `flops` are those of the WHOLE product, a sub-range launch (p.tile0 / p.tile_cnt) is credited its share of tiles
     const int tail = gemm_tail_tiles(p, batch);
     const int tiles = p.tri ? p.nt * (p.nt + 1) / 2 + (p.mt - p.nt) * p.nt : p.mt * p.nt;
+    const int t0 = p.tile0, t1 = p.tile_cnt > 0 ? (t0 + p.tile_cnt < tiles ? t0 + p.tile_cnt : tiles) : tiles;
+    const int big_end = t1 < tiles - tail ? t1 : tiles - tail;
     hipError_t r = hipSuccess;
-    for (int part = 1; part <= (tail > 0 ? 2 : 1) && r == hipSuccess; ++part) {
+    for (int part = 1; part <= 2 && r == hipSuccess; ++part) {
+      const int mine = part == 1 ? (gemm_uses_small_tiles(p, batch) ? (t0 == 0 ? tiles : 0) : big_end - t0)
+                                 : ((tail > 0 && t1 == tiles) ? tail : 0);
+      if (mine <= 0) continue;
       if (h->gemm_ev_used + 2 > h->gemm_ev.size()) {
         for (int i = 0; i < 64; ++i) {
           hipEvent_t e;
@@ -230,12 +249,11 @@ static hipError_t prof_gemm(mi_gp_handle* h, const GemmParams& p, int ak, int bk
       (void)hipEventRecord(h->gemm_ev[h->gemm_ev_used + 1], st);
       const size_t pair = h->gemm_ev_used / 2;
       if (h->gemm_ev_big.size() <= pair) { h->gemm_ev_big.resize(pair + 64); h->gemm_ev_flops.resize(pair + 64); }
-      const double share = tail > 0 ? (part == 1 ? (double)(tiles - tail) : (double)tail) / (double)tiles : 1.0;
       h->gemm_ev_big[pair] = (part == 1 && !gemm_uses_small_tiles(p, batch)) ? 1 : 0;
-      h->gemm_ev_flops[pair] = flops * share;
+      h->gemm_ev_flops[pair] = flops * (double)mine / (double)tiles;
+      h->gemm_flops_acc += flops * (double)mine / (double)tiles;
       h->gemm_ev_used += 2;
     }
-    h->gemm_flops_acc += flops;
     return r;
   }
   return launch_gemm_f64(p, ak, bk, batch, st);
@@ -243,9 +261,12 @@ static hipError_t prof_gemm(mi_gp_handle* h, const GemmParams& p, int ak, int bk
 
 // trapezoid update  A[r0:, c0:c0+nc] -= P P_c^T  with P = A[r0:, k0:k0+kw] (tile units)
 static hipError_t syrk_trapezoid(mi_gp_handle* h, double* A, long lda, int ntr, int r0, int nc, int k0, int kw,
-                                 hipStream_t st, int one_per_cu = 0) {
+                                 hipStream_t st, int one_per_cu = 0, int tile0 = 0, int tile_cnt = 0, int fc = 0) {
   GemmParams p;
   p.one_per_cu = one_per_cu;
+  p.tile0 = tile0;
+  p.tile_cnt = tile_cnt;
+  p.fc = fc;
   p.hiprio = (st == h->pstream && h->chain_prio) ? 1 : 0;
   p.small_below = h->small_below;
   p.tail_small = h->tail_small;
@@ -357,7 +378,43 @@ static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int nt
     const int n1 = J + w;  // first tile column right of this super-panel
     if (P != T) CKE(hand_off(h, P, T));  // the main stream may read super-panel J from here on
     if (n1 >= ntc) break;
+    // The END of a large factorisation is a small one: below LOOKAHEAD_MIN_TILES trailing columns the cross-stream hand-offs
+    // cost more than the overlap returns (that is why small problems run on one stream), so the rest runs on the main
+    // stream alone (round 4, option 21; the super-panel widths stay what they were, so the arithmetic does not change).
+    if (P != T && h->lookahead != 2 && ntc - n1 <= h->single_below) P = T;
     const int wn = pick_w(h, ntc - n1, wcap);
+    const bool bulk = n1 + wn < ntc;
+    // tiles of the trailing update of columns [n1 + wn, ntc) / of the whole trailing trapezoid [n1, ntc)
+    const int bc = ntc - n1 - wn, br = ntr - n1 - wn;
+    const int btiles = bc * (bc + 1) / 2 + (br - bc) * bc;
+    const int low = ntc - n1 <= h->lowocc_thr ? 1 : 0;
+    if (P != T && bulk && h->merge_min_tiles > 0 && ntc - n1 >= h->merge_min_tiles) {
+      // BULK-BOUND super-panels (round 4): the panel stream idles for most of such a step, so the next super-panel need not
+      // be updated by launches of its own ((a1) on the panel stream + (a2) on the main stream, 64x64 tiles, ~55 TFLOP/s, a
+      // last partial round each).  The whole trailing trapezoid [n1, ntc) is ONE enumeration on the 128x128-tile kernel with
+      // the next super-panel's wn columns first; a prefix of full rounds that covers them runs two workgroups per CU with
+      // nothing beside it, the panel stream starts behind it, and the rest follows as below (one per CU beside the chain,
+      // then two per CU).  Same tiles and k order per tile as the split form.
+      const int ac = ntc - n1, ar = ntr - n1;
+      const int atiles = ac * (ac + 1) / 2 + (ar - ac) * ac;
+      const int ft = wn * (wn + 1) / 2 + (ar - wn) * wn;
+      int x1 = (ft + 511) / 512 * 512;
+      if (x1 > atiles) x1 = atiles;
+      CKE(syrk_trapezoid(h, A, lda, ntr, n1, ac, J, w, T, 0, 0, x1, wn));
+      CKE(hand_off(h, T, P));
+      int done = x1;
+      if (low && h->split_tiles > 0 && atiles - done >= h->split_tiles + h->split_min_rest) {
+        CKE(syrk_trapezoid(h, A, lda, ntr, n1, ac, J, w, T, 1, done, h->split_tiles, wn));
+        done += h->split_tiles;
+        CKE(syrk_trapezoid(h, A, lda, ntr, n1, ac, J, w, T, 0, done, atiles, wn));
+      } else if (atiles > done) {
+        CKE(syrk_trapezoid(h, A, lda, ntr, n1, ac, J, w, T, low, done, atiles, wn));
+      }
+      CKE(chol_panel(h, A, lda, ntr, n1, wn, P));
+      J = n1;
+      w = wn;
+      continue;
+    }
     if (P != T) {
       // (a1) the next super-panel's FIRST tile column on the panel stream itself: the chain goes on to its leaf without
       //      waiting for the other wn - 1 columns (round 1 updated all wn columns on the main stream first: 40-80 us on
@@ -382,8 +439,18 @@ static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int nt
     // (On a single stream the order cannot matter for the schedule; there the bulk update stays behind the chain, where
     // it measures 1.6 % faster -- 1.771 vs 1.800 ms per launch at N = 16384, same box, interleaved: it then starts after
     // ~0.5 ms of a mostly idle chip instead of straight after the next-panel update.)
-    const bool bulk = n1 + wn < ntc;
-    if (bulk && P != T) CKE(syrk_trapezoid(h, A, lda, ntr, n1 + wn, ntc - n1 - wn, J, w, T, ntc - n1 <= h->lowocc_thr ? 1 : 0));
+    if (bulk && P != T) {
+      // Early super-panels are bound by the bulk update, not by the chain (the panel stream idles for most of it): only the
+      // first split_tiles tiles run one workgroup per CU -- the mode that leaves every CU room for the chain's leaf /
+      // strip / in-panel workgroups but costs the kernel ~10 % -- and the rest runs two per CU once the chain is through
+      // (same tiles, same kernels: bit-identical results).  split_tiles ~ what the update gets done while a chain runs.
+      if (low && h->split_tiles > 0 && btiles >= h->split_tiles + h->split_min_rest) {
+        CKE(syrk_trapezoid(h, A, lda, ntr, n1 + wn, bc, J, w, T, 1, 0, h->split_tiles));
+        CKE(syrk_trapezoid(h, A, lda, ntr, n1 + wn, bc, J, w, T, 0, h->split_tiles, btiles));
+      } else {
+        CKE(syrk_trapezoid(h, A, lda, ntr, n1 + wn, bc, J, w, T, low));
+      }
+    }
     CKE(chol_panel(h, A, lda, ntr, n1, wn, P));
     if (bulk && P == T) CKE(syrk_trapezoid(h, A, lda, ntr, n1 + wn, ntc - n1 - wn, J, w, T, 0));
     J = n1;

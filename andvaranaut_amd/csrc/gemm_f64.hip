@@ -87,6 +87,20 @@ __device__ __forceinline__ void tile_from_index_banded(const GemmParams& p, int 
   tile_from_index_banded(p.tri, p.mt, p.nt, idx, R, ti, tj);
 }
 
+// First-columns-first enumeration of the lower trapezoid (GemmParams::fc): the fc leading tile columns row by row, then the
+// sub-trapezoid of the remaining columns in the banded order.
+__device__ __forceinline__ void tile_from_index_fc(int mt, int nt, int fc, int band, int idx, int& ti, int& tj) {
+  const int ft = fc * (fc + 1) / 2 + (mt - fc) * fc;
+  if (idx < ft) {
+    tile_from_index(1, fc, idx, ti, tj);
+  } else {
+    if (band > 0) tile_from_index_banded(1, mt - fc, nt - fc, idx - ft, band, ti, tj);
+    else tile_from_index(1, nt - fc, idx - ft, ti, tj);
+    ti += fc;
+    tj += fc;
+  }
+}
+
 // Panel-list mode (GemmParams::pl): tile `idx` of the launch -> tile-unit coordinates of its A rows, B rows, C rows and C
 // columns, and whether it is a diagonal tile of its panel's trapezoid.  The table walk is uniform per workgroup (scalar loads).
 __device__ __forceinline__ void list_tile(const GemmParams& p, int idx, int& ra, int& rb, int& rc, int& cc, bool& diag) {
@@ -167,6 +181,7 @@ __global__ __launch_bounds__(vb::NT_B, 2) void gemm_f64_kernel_b(GemmParams p) {
     const int b = blockIdx.x, x = b & 7, q = nblk >> 3, r = nblk & 7;
     idx = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
   }
+  idx += p.tile0;  // sub-range launch: the XCD-aware order above is taken inside the range
   int ti, tj;
   int rc, cc;  // C tile row / column (differ from the operand rows ti / tj only in panel-list mode)
   if (p.pl) {
@@ -174,7 +189,8 @@ __global__ __launch_bounds__(vb::NT_B, 2) void gemm_f64_kernel_b(GemmParams p) {
     list_tile(p, idx, ti, tj, rc, cc, diag);
   } else {
     // (full rectangles measured neutral: 8192^3 75.2 vs 75.7 TFLOP/s -- the row-major order stays for them)
-    if (p.band > 0 && p.tri && p.kmode == 0) tile_from_index_banded(p, idx, p.band, ti, tj);
+    if (p.fc > 0) tile_from_index_fc(p.mt, p.nt, p.fc, p.band, idx, ti, tj);
+    else if (p.band > 0 && p.tri && p.kmode == 0) tile_from_index_banded(p, idx, p.band, ti, tj);
     else tile_from_index(p, idx, ti, tj);
     if (p.kmode == 2) ti = p.mt - 1 - ti;
     if (p.kmode == 4 && !p.tri) { tj = p.nt - 1 - idx / p.mt; ti = idx % p.mt; }  // longest-k columns first (LPT order)
@@ -426,7 +442,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel_s(GemmParams p) {
       // tail of a 128x128-tile launch: this workgroup is one quadrant of parent tile sub_base + blockIdx.x / 4
       int pti, ptj;
       const int pidx = p.sub_base + ((int)blockIdx.x >> 2), quad = (int)blockIdx.x & 3;
-      if (p.band > 0 && p.tri) tile_from_index_banded(p.tri, p.sub_mt, p.sub_nt, pidx, p.band, pti, ptj);
+      if (p.fc > 0) tile_from_index_fc(p.sub_mt, p.sub_nt, p.fc, p.band, pidx, pti, ptj);
+      else if (p.band > 0 && p.tri) tile_from_index_banded(p.tri, p.sub_mt, p.sub_nt, pidx, p.band, pti, ptj);
       else tile_from_index(p.tri, p.sub_nt, pidx, pti, ptj);
       ti = 2 * pti + (quad >> 1);
       tj = 2 * ptj + (quad & 1);
@@ -627,6 +644,7 @@ hipError_t launch_gemm_f64(const GemmParams& p_in, int opA_kmajor, int opB_kmajo
   // while bands of 8 rows x 8 columns touch 16 MB per 64 tiles (15360 x 1024, k = 1024 on 128x128 tiles: 545 vs 558 us;
   // 8192 x 1024: 253 vs 264 us).  Wide trapezoids (the bulk updates) keep the band-column-major order of section 5.1.
   if (p.tri && !p.pl && p.nt <= NARROW_TRAPEZOID_COLS) p.band = 0;
+  if (!(p.tri && !p.pl && p.kmode == 0 && p.fc > 0 && p.fc < p.nt)) p.fc = 0;
   const int nblk = tile_count(p);
   if (nblk <= 0 || batch <= 0) return hipSuccess;
   const bool small = gemm_uses_small_tiles(p, batch);
@@ -656,9 +674,13 @@ hipError_t launch_gemm_f64(const GemmParams& p_in, int opA_kmajor, int opB_kmajo
     else gemm_f64_kernel_s<true, false><<<grid, block, pad, stream>>>(q);
     return hipGetLastError();
   };
-  if (small) return part == 2 ? hipSuccess : launch_small(0);
-  if (part != 2) {
-    dim3 grid(nblk - tail, 1, batch), block(vb::NT_B);
+  if (small) return (part == 2 || p.tile0 > 0) ? hipSuccess : launch_small(0);  // small launches are never split
+  // sub-range [t0, t1) of the enumeration: the 128x128-tile kernel takes what lies in front of the tail, the tail goes
+  // with the range that reaches the end
+  const int t0 = p.tile0, t1 = p.tile_cnt > 0 ? (t0 + p.tile_cnt < nblk ? t0 + p.tile_cnt : nblk) : nblk;
+  const int big_end = t1 < nblk - tail ? t1 : nblk - tail;
+  if (part != 2 && big_end > t0) {
+    dim3 grid(big_end - t0, 1, batch), block(vb::NT_B);
     const size_t lds = p.one_per_cu ? LDS_ONE_PER_CU : sizeof(double) * 4 * vb::OPER_B;
     if (!opA_kmajor && !opB_kmajor) gemm_f64_kernel_b<false, false><<<grid, block, lds, stream>>>(p);
     else if (!opA_kmajor && opB_kmajor) gemm_f64_kernel_b<false, true><<<grid, block, lds, stream>>>(p);
@@ -667,7 +689,7 @@ hipError_t launch_gemm_f64(const GemmParams& p_in, int opA_kmajor, int opB_kmajo
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
-  return (tail > 0 && part != 1) ? launch_small(tail) : hipSuccess;
+  return (tail > 0 && part != 1 && t1 == nblk) ? launch_small(tail) : hipSuccess;
 }
 
 hipError_t gemm_f64_enable_lds() {

@@ -25,6 +25,14 @@ struct GemmParams {
                                     // the panel chain's leaf / strip kernels next to a bulk update)
   int tail_small = 1;               // uniform-k 128x128-tile launches: the tiles beyond the last full round of 512 go to the
                                     // 64x64-tile kernel in a second launch (mi_gp_set_option 9)
+  // 128x128-tile launches only: restrict the launch to tiles [tile0, tile0 + tile_cnt) of the enumeration (tile_cnt 0: all).
+  // The Cholesky driver splits a bulk update into a part that runs one workgroup per CU beside the panel chain and a part
+  // that runs two per CU after it (mi_gp_set_option 18); which kernel computes which tile does not depend on the split.
+  int tile0 = 0, tile_cnt = 0;
+  // uniform-k trapezoid launches on the 128x128-tile kernel: enumerate the tiles of the first `fc` tile columns first (row by
+  // row, like a narrow trapezoid), then the rest in the banded order.  With a sub-range launch over a prefix this lets the
+  // driver finish the NEXT super-panel's columns ahead of the rest of a trailing update inside ONE enumeration.
+  int fc = 0;
   // set by the launcher for that second launch: 64x64 tile 4 e + quadrant belongs to 128x128 tile sub_base + e of the
   // parent enumeration (sub_mt x sub_nt tiles of 128); -1: off
   int sub_base = -1, sub_mt = 0, sub_nt = 0;

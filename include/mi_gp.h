@@ -124,7 +124,12 @@ int mi_gp_predict_grad(mi_gp_handle* h, const double* Xnew_dev, int m, double* w
  *      kernel (default 1: a last round with few tiles costs a whole round; sharded N=65536 on one rank 1.52 -> 1.47 s)
  *   14 band height (tile rows) of the band-column-major tile order of uniform-k trapezoid launches (default 8, 0 = row-major)
  *   16 panel-stream GEMM launches raise their waves' issue priority (s_setprio 3) against the bulk update's (default 1)
- * 8, 14 and 16 only change scheduling (bit-identical results); 2, 4-7, 9 regroup sums (agreement to rounding), and so does 0 where
+ *   18 tiles of a bulk update that run one workgroup per CU beside the panel chain, the rest two per CU (default 2048, 0: no split)
+ *   19 ... only when at least this many tiles remain for the second part (default 1024)
+ *   20 trailing tile columns from which the next super-panel's update rides at the head of the trailing update's tile
+ *      enumeration instead of in launches of its own (default 72, 0: never)
+ *   21 trailing tile columns at or below which a two-stream factorisation continues on the main stream alone (default 16)
+ * 8, 14, 16, 18, 19 and 21 only change scheduling (bit-identical results); 20 moves tiles between the two GEMM kernels (same k order); 2, 4-7, 9 regroup sums (agreement to rounding), and so does 0 where
  * it changes the super-panel width (36 to 64 tile columns).
  * Unknown ids return -1.  (Round 1's options 1, 3, 10-13 -- GEMM variants, hipGraph replay, persistent bulk kernels,
  * exclusive leaf, fused leaf + strip -- are gone with the code they selected.) */

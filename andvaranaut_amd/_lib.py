@@ -34,6 +34,17 @@ class MiGpBuffers(ctypes.Structure):
     ]
 
 
+class MiGpBatchBuffers(ctypes.Structure):
+    _fields_ = [
+        ("K_dev", ctypes.c_void_p),
+        ("Z_dev", ctypes.c_void_p),
+        ("W_dev", ctypes.c_void_p),
+        ("stride_k", ctypes.c_long),
+        ("stride_zw", ctypes.c_long),
+        ("count", ctypes.c_int),
+    ]
+
+
 class MiGpShardConfig(ctypes.Structure):
     _fields_ = [
         ("n", ctypes.c_int),
@@ -73,6 +84,7 @@ def load():
     lib = ctypes.CDLL(LIB_PATH)
     vp, ci, cl, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_double
     dp = ctypes.POINTER(ctypes.c_double)
+    ip = ctypes.POINTER(ctypes.c_int)
     lib.mi_gp_last_global_error.restype = ctypes.c_char_p
     lib.mi_gp_last_error.restype = ctypes.c_char_p
     lib.mi_gp_last_error.argtypes = [vp]
@@ -87,6 +99,9 @@ def load():
     lib.mi_gp_lml.argtypes = [vp, dp, dp]
     lib.mi_gp_lml_parts.argtypes = [vp, dp, dp]
     lib.mi_gp_lml_grad.argtypes = [vp, dp, dp, dp]
+    lib.mi_gp_set_batch.argtypes = [vp, ctypes.POINTER(MiGpBatchBuffers)]
+    lib.mi_gp_lml_batch.argtypes = [vp, ci, dp, dp, ip]
+    lib.mi_gp_lml_grad_batch.argtypes = [vp, ci, dp, dp, dp, ip]
     lib.mi_gp_alpha.argtypes = [vp, dp]
     lib.mi_gp_grad_x.argtypes = [vp, vp]
     lib.mi_gp_set_diag.argtypes = [vp, vp]
@@ -97,7 +112,6 @@ def load():
     lib.mi_gp_set_option.argtypes = [vp, ci, ci]
     lib.mi_gp_set_profiling.argtypes = [vp, ci]
     lib.mi_gp_timers.argtypes = [vp, dp, ci]
-    ip = ctypes.POINTER(ctypes.c_int)
     lib.mi_gp_assemble_block.argtypes = [ci, ci, ip, ip, vp, vp, ci, vp, ci, ci, ci, vp, cl, ci, ci, ci, vp]
     lib.mi_gp_chol_panel.argtypes = [vp, cl, ci, ci, vp, vp, ci, vp]
     lib.mi_gp_lml_partial.argtypes = [vp, cl, vp, ci, vp, vp]
@@ -137,6 +151,9 @@ EXPORTS = [
     "mi_gp_lml",
     "mi_gp_lml_parts",
     "mi_gp_lml_grad",
+    "mi_gp_set_batch",
+    "mi_gp_lml_batch",
+    "mi_gp_lml_grad_batch",
     "mi_gp_alpha",
     "mi_gp_grad_x",
     "mi_gp_set_diag",

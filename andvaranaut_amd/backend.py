@@ -129,6 +129,73 @@ class MiGP:
         self.info = self._check(self.lib.mi_gp_lml_grad(self.h, tp, ctypes.byref(out), gp_), "mi_gp_lml_grad")
         return out.value, grad
 
+    # ------------------------------------------------------------------ batched evaluation
+    def _ensure_batch(self, k, need_grad):
+        """Device buffers for k problems in lockstep (mi_gp_set_batch): K (+ Z, W for the gradient) as ONE tensor each."""
+        have = getattr(self, "_batch_k", 0)
+        if have >= k and (not need_grad or self._bZ is not None):
+            return
+        k = max(k, have)
+        with torch.cuda.device(self.dev):
+            self._bK = torch.empty((k, self.np_ + 128, self.lda), dtype=torch.float64, device=self.dev)
+            self._bZ = self._bW = None
+            if need_grad or getattr(self, "_batch_grad", False):
+                self._bZ = torch.zeros((k, self.np_, self.lda), dtype=torch.float64, device=self.dev)
+                self._bW = torch.zeros((k, self.np_, self.lda), dtype=torch.float64, device=self.dev)
+                self._batch_grad = True
+            torch.cuda.synchronize(self.dev)
+        b = _lib.MiGpBatchBuffers()
+        b.K_dev = self._bK.data_ptr()
+        b.Z_dev = self._bZ.data_ptr() if self._bZ is not None else None
+        b.W_dev = self._bW.data_ptr() if self._bW is not None else None
+        b.stride_k = (self.np_ + 128) * self.lda
+        b.stride_zw = self.np_ * self.lda
+        b.count = k
+        self._check(self.lib.mi_gp_set_batch(self.h, ctypes.byref(b)), "mi_gp_set_batch")
+        self._batch_k = k
+
+    def _thetas(self, thetas):
+        th = np.ascontiguousarray(thetas, dtype=np.float64)
+        if th.ndim != 2 or th.shape[1] != self.ntheta:
+            raise ValueError(f"thetas must be (k, {self.ntheta})")
+        return th
+
+    def lml_batch(self, thetas):
+        """LML at k hyper-parameter vectors of the same data in ONE lockstep evaluation (mi_gp_lml_batch): every launch
+        carries blockIdx.z = problem.  Returns (k,) values, -inf where the covariance is not positive definite; the
+        values are those lml() returns one at a time."""
+        th = self._thetas(thetas)
+        k = th.shape[0]
+        self._ensure_batch(k, False)
+        self._factored_ok = False
+        out = np.empty(k)
+        info = np.zeros(k, dtype=np.int32)
+        if self._bad_data:
+            return np.full(k, -np.inf)
+        dpt, ipt = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)
+        self._check(self.lib.mi_gp_lml_batch(self.h, k, th.ctypes.data_as(dpt), out.ctypes.data_as(dpt), info.ctypes.data_as(ipt)),
+                    "mi_gp_lml_batch")
+        self.batch_info = info
+        return out
+
+    def lml_grad_batch(self, thetas):
+        """(LML (k,), dLML/dtheta (k, ntheta)) at k hyper-parameter vectors in one lockstep evaluation
+        (mi_gp_lml_grad_batch); rows of non-positive-definite problems are (-inf, zeros)."""
+        th = self._thetas(thetas)
+        k = th.shape[0]
+        self._ensure_batch(k, True)
+        self._factored_ok = False
+        out = np.empty(k)
+        grad = np.zeros((k, self.ntheta))
+        info = np.zeros(k, dtype=np.int32)
+        if self._bad_data:
+            return np.full(k, -np.inf), grad
+        dpt, ipt = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)
+        self._check(self.lib.mi_gp_lml_grad_batch(self.h, k, th.ctypes.data_as(dpt), out.ctypes.data_as(dpt),
+                                                  grad.ctypes.data_as(dpt), info.ctypes.data_as(ipt)), "mi_gp_lml_grad_batch")
+        self.batch_info = info
+        return out, grad
+
     def lml_grad_data(self, theta, want_x=True):
         """(LML, dLML/dtheta, dLML/dy, dLML/dX) -- the data-side gradients drive the chain rule through
         warps (cwgp / iwgp) and free input rows (inverse_opt).  dLML/dX is None unless want_x."""

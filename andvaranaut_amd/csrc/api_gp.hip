@@ -59,6 +59,14 @@ struct mi_gp_handle {
   double t_assemble_ms, t_chol_ms, t_reduce_ms, t_gemm_ms, t_total_ms, gemm_flops, n_gemm;
   double t_trtri_ms, t_lauum_ms, t_contract_ms;
   double t_gemm_big_ms, gemm_big_flops, n_gemm_big;  // the 128x128-tile kernel only
+  // batched evaluation (mi_gp_set_batch / mi_gp_lml_batch / mi_gp_lml_grad_batch): while a batch runs, buf / the scratch
+  // pointers above point at the batch's arrays and bt carries the strides; nullptr / nb = 1 otherwise
+  Batch bt;
+  const Batch* btp;        // &bt while a batch is being enqueued, nullptr otherwise (what the launchers get)
+  mi_gp_batch_buffers bbuf;
+  int batch_cap;           // problems the batch scratch below is sized for
+  double *b_theta_dev, *b_dinv_dev, *b_alpha_dev, *b_part_dev, *b_grad_host, *b_out_host, *b_theta_host;
+  int* b_info_dev;
   bool factored;
   bool have_u;             // Z_dev holds U = L^-T and alpha_dev = K^-1 y of the last mi_gp_factor (mi_gp_predict_grad)
   bool have_kinv;          // W_dev holds K^-1 (lower) and alpha_dev = K^-1 y of the last mi_gp_lml_grad
@@ -85,6 +93,11 @@ static void release_handle(mi_gp_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   (void)hipFree(h->theta_dev); (void)hipFree(h->dinv_dev); (void)hipFree(h->info_dev);
   (void)hipFree(h->alpha_dev); (void)hipFree(h->part_dev); (void)hipFree(h->gxs_dev);
+  (void)hipFree(h->b_theta_dev); (void)hipFree(h->b_dinv_dev); (void)hipFree(h->b_alpha_dev); (void)hipFree(h->b_part_dev);
+  (void)hipFree(h->b_info_dev);
+  if (h->b_grad_host) (void)hipHostFree(h->b_grad_host);
+  if (h->b_out_host) (void)hipHostFree(h->b_out_host);
+  if (h->b_theta_host) (void)hipHostFree(h->b_theta_host);
   if (h->grad_host) (void)hipHostFree(h->grad_host);
   if (h->out_host) (void)hipHostFree(h->out_host);
   if (h->theta_host) (void)hipHostFree(h->theta_host);
@@ -275,7 +288,7 @@ static hipError_t syrk_trapezoid(mi_gp_handle* h, double* A, long lda, int ntr, 
   p.B = p.A;
   p.C = A + (long)r0 * 128 * lda + (long)r0 * 128;
   p.lda = p.ldb = p.ldc = lda;
-  p.strideA = p.strideB = p.strideC = 0;
+  p.strideA = p.strideB = p.strideC = h->btp ? h->btp->sK : 0;
   p.mt = ntr - r0;
   p.nt = nc;
   p.k = kw * 128;
@@ -288,7 +301,7 @@ static hipError_t syrk_trapezoid(mi_gp_handle* h, double* A, long lda, int ntr, 
   // (full diagonal tiles, a 128-row tile for the y row).
   const double c = nc * 128.0, rows_real = (p.mt - 1) * 128.0;
   const double flops = (double)p.k * (c * (c + 1.0) + 2.0 * (rows_real - c) * c + 2.0 * c);
-  return prof_gemm(h, p, 0, 0, 1, flops, st);
+  return prof_gemm(h, p, 0, 0, h->btp ? h->btp->nb : 1, flops, st);
 }
 
 // factor tile columns [c0, c0+w) of the (ntr x ntc)-tile trapezoid, recursively halving w
@@ -300,8 +313,8 @@ static hipError_t chol_panel(mi_gp_handle* h, double* A, long lda, int ntr, int 
     const int m = (ntr - c0 - 1) * 128;
     // (the trapezoid's last tile row is the y^T block: below the last tile column there is nothing else, and the leaf
     // solves that one row itself)
-    e = launch_potrf_leaf128(blk, lda, dinv, c0 * 128, h->info_dev, st, m == 128 ? blk + 128 * lda : nullptr);
-    if (e == hipSuccess && m > 128) e = launch_trsm_strip128(dinv, blk + 128 * lda, lda, m, st);
+    e = launch_potrf_leaf128(blk, lda, dinv, c0 * 128, h->info_dev, st, m == 128 ? blk + 128 * lda : nullptr, h->btp);
+    if (e == hipSuccess && m > 128) e = launch_trsm_strip128(dinv, blk + 128 * lda, lda, m, st, h->btp, h->btp ? h->btp->sK : 0);
     if (e == hipSuccess && c0 == h->wait_col) {  // the super-panel's other columns are being updated on the main stream
       h->wait_col = -1;
       e = hipStreamWaitEvent(st, h->wait_ev, 0);
@@ -466,14 +479,15 @@ static int enqueue_factor(mi_gp_handle* h, int noise_form, bool prof) {
   if (prof) (void)hipEventRecord(h->ev[0], h->stream);
   // first kernel of the evaluation: y rows, the bad-pivot word, and theta from the pinned host buffer to theta_dev
   HCK(launch_set_yrows(h->buf.K_dev, h->buf.lda, h->np, h->np, h->buf.y_dev, h->n, h->stream, h->info_dev, h->theta_host,
-                       h->theta_dev, h->ntheta), "set_yrows");
+                       h->theta_dev, h->ntheta, h->btp), "set_yrows");
   HCK(launch_assemble(h->spec, h->theta_dev, h->buf.X_dev, h->n, h->buf.X_dev, h->n, h->buf.K_dev, h->buf.lda, h->np,
-                      h->np, 1, noise_form, h->stream, 0, h->diag_dev), "assemble");
+                      h->np, 1, noise_form, h->stream, 0, h->diag_dev, h->btp), "assemble");
   if (prof) (void)hipEventRecord(h->ev[1], h->stream);
   HCK(cholesky(h, h->buf.K_dev, h->buf.lda, h->ntc + 1, h->ntc), "cholesky");
   if (prof) (void)hipEventRecord(h->ev[2], h->stream);
   // the scalars go straight to the pinned host buffer (device-visible): no download launch behind the reduction
-  HCK(launch_lml_reduce(h->buf.K_dev, h->buf.lda, h->buf.K_dev + (long)h->np * h->buf.lda, h->n, h->out_host, h->stream, h->info_dev), "lml_reduce");
+  HCK(launch_lml_reduce(h->buf.K_dev, h->buf.lda, h->buf.K_dev + (long)h->np * h->buf.lda, h->n, h->out_host, h->stream, h->info_dev,
+                        h->btp), "lml_reduce");
   if (prof) (void)hipEventRecord(h->ev[3], h->stream);
   return 0;
 }
@@ -577,12 +591,17 @@ extern "C" int mi_gp_timers(mi_gp_handle* h, double* out, int n) {
 // then Kinv = U U^T (lower tiles, W_dev), alpha = U beta, and the contraction kernel.
 static hipError_t gemm_call(mi_gp_handle* h, int ak, int bk, const double* A, long lda, long sA, const double* B, long ldb,
                             long sB, double* C, long ldc, long sC, int mt, int nt, int k, int tri, int kmode,
-                            double alpha, double beta, int batch) {
+                            double alpha, double beta, int batch, long zA = 0, long zB = 0, long zC = 0) {
   GemmParams p;
   p.A = A; p.B = B; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.strideA = sA; p.strideB = sB; p.strideC = sC;
   p.mt = mt; p.nt = nt; p.k = k; p.tri = tri; p.kmode = kmode; p.alpha = alpha; p.beta = beta;
   p.small_below = h->small_below; p.band = h->band_rows; p.tail_small = h->tail_small;
+  if (h->btp) {  // batched evaluation: the problems are the second batch level (zA / zB / zC: the strides of the matrices A, B, C live in)
+    p.batch1 = batch;
+    p.strideA2 = zA; p.strideB2 = zB; p.strideC2 = zC;
+    batch *= h->btp->nb;
+  }
   return launch_gemm_f64(p, ak, bk, batch, h->stream);
 }
 
@@ -592,10 +611,11 @@ static hipError_t inverse_transpose(mi_gp_handle* h) {
   double* T = h->buf.W_dev;
   const long ld = h->buf.lda;
   const int ntc = h->ntc;
-  hipError_t e = launch_set_identity_blocks(U, ld, ntc, h->stream);
+  const long zK = h->btp ? h->btp->sK : 0, zZ = h->btp ? h->btp->sZ : 0, zW = h->btp ? h->btp->sW : 0;
+  hipError_t e = launch_set_identity_blocks(U, ld, ntc, h->stream, h->btp);
   if (e != hipSuccess) return e;
   // leaves: X L_kk^T = I  ->  X = L_kk^-T
-  e = launch_trsm_strip128_batched(h->dinv_dev, U, ld, 128 * ld + 128, 128, ntc, h->stream);
+  e = launch_trsm_strip128_batched(h->dinv_dev, U, ld, 128 * ld + 128, 128, ntc, h->stream, h->btp, zZ);
   if (e != hipSuccess) return e;
   for (int s = 1; s < ntc; s *= 2) {
     const int nfull = ntc / (2 * s);             // nodes whose second half is complete
@@ -613,10 +633,10 @@ static hipError_t inverse_transpose(mi_gp_handle* h) {
       double* P = T + off + (long)s * 128;
       double* U12 = U + off + (long)s * 128;
       // P = U11 L21^T   (U11 upper triangular: k >= row tile)
-      e = gemm_call(h, 0, 0, U11, ld, node, L21, ld, node, P, ld, node, s, s2, s * 128, 0, 3, 1.0, 0.0, batch);
+      e = gemm_call(h, 0, 0, U11, ld, node, L21, ld, node, P, ld, node, s, s2, s * 128, 0, 3, 1.0, 0.0, batch, zZ, zK, zW);
       if (e != hipSuccess) return e;
       // U12 = -P U22    (U22 upper triangular: k <= column tile)
-      e = gemm_call(h, 0, 1, P, ld, node, U22, ld, node, U12, ld, node, s, s2, s2 * 128, 0, 4, -1.0, 0.0, batch);
+      e = gemm_call(h, 0, 1, P, ld, node, U22, ld, node, U12, ld, node, s, s2, s2 * 128, 0, 4, -1.0, 0.0, batch, zW, zZ, zZ);
       if (e != hipSuccess) return e;
     }
   }
@@ -630,13 +650,14 @@ static int enqueue_gradient(mi_gp_handle* h, bool prof) {
   if (prof) (void)hipEventRecord(h->ev[5], h->stream);
   const long ld = h->buf.lda;
   // Kinv = U U^T, lower tiles only, k >= row tile
+  const long zZ = h->btp ? h->btp->sZ : 0, zW = h->btp ? h->btp->sW : 0;
   HCK(gemm_call(h, 0, 0, h->buf.Z_dev, ld, 0, h->buf.Z_dev, ld, 0, h->buf.W_dev, ld, 0, h->ntc, h->ntc, h->np, 1, 3, 1.0,
-                0.0, 1), "lauum");
+                0.0, 1, zZ, zZ, zW), "lauum");
   if (prof) (void)hipEventRecord(h->ev[6], h->stream);
-  HCK(launch_trmv_upper(h->buf.Z_dev, ld, h->buf.K_dev + (long)h->np * ld, h->n, h->alpha_dev, h->stream), "trmv");
+  HCK(launch_trmv_upper(h->buf.Z_dev, ld, h->buf.K_dev + (long)h->np * ld, h->n, h->alpha_dev, h->stream, h->btp), "trmv");
   // the final reduction writes the gradient straight into the handle's pinned host buffer (device-visible)
   HCK(launch_grad_contract(h->spec, h->theta_dev, h->buf.X_dev, h->n, h->buf.W_dev, ld, h->alpha_dev, h->part_dev,
-                           h->grad_host, h->stream), "grad_contract");
+                           h->grad_host, h->stream, h->btp), "grad_contract");
   if (prof) (void)hipEventRecord(h->ev[7], h->stream);
   return 0;
 }
@@ -693,6 +714,106 @@ extern "C" int mi_gp_set_diag(mi_gp_handle* h, const double* diag_dev) {
   h->factored = false;
   h->have_kinv = false;
   return 0;
+}
+
+// ---------------------------------------------------------------- batched evaluation
+// K covariances of the SAME inputs (one theta each) factorised in lockstep: every launch of the evaluation carries
+// blockIdx.z = problem.  One evaluation below N ~ 10^4 is bound by its serial panel chain (leaf -> strip -> update per 128
+// columns) and leaves most of the chip idle; MAP restarts (gpmcmc.py:328-343) and the NUTS chains that share a GPU
+// (gpmcmc.py:351) evaluate the same data at different theta, so their chains can run side by side inside the same launches
+// instead of on separate handles and streams (which stops paying at the fourth handle: hardware queues).
+extern "C" int mi_gp_set_batch(mi_gp_handle* h, const mi_gp_batch_buffers* b) {
+  if (!h || !b || !b->K_dev || b->count < 1) return -1;
+  const long need_k = (long)(h->np + 128) * h->buf.lda, need_z = (long)h->np * h->buf.lda;
+  if (!h->have_data) { snprintf(h->err, sizeof(h->err), "mi_gp_set_batch: call mi_gp_set_data first (lda is taken from it)"); return -1; }
+  if (b->stride_k < need_k || ((b->Z_dev || b->W_dev) && b->stride_zw < need_z) || (b->stride_k & 1) || (b->stride_zw & 1)) {
+    snprintf(h->err, sizeof(h->err), "mi_gp_set_batch: strides must be even and >= (np + 128) * lda = %ld (K), np * lda = %ld (Z, W)", need_k, need_z);
+    return -1;
+  }
+  HCK(hipSetDevice(h->device), "hipSetDevice");
+  if (b->count > h->batch_cap) {
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(h->b_theta_dev); (void)hipFree(h->b_dinv_dev); (void)hipFree(h->b_alpha_dev); (void)hipFree(h->b_part_dev);
+    (void)hipFree(h->b_info_dev);
+    if (h->b_grad_host) (void)hipHostFree(h->b_grad_host);
+    if (h->b_out_host) (void)hipHostFree(h->b_out_host);
+    if (h->b_theta_host) (void)hipHostFree(h->b_theta_host);
+    h->b_theta_dev = h->b_dinv_dev = h->b_alpha_dev = h->b_part_dev = h->b_grad_host = h->b_out_host = h->b_theta_host = nullptr;
+    h->b_info_dev = nullptr;
+    h->batch_cap = 0;
+    const size_t k = (size_t)b->count;
+    HCK(hipMalloc(&h->b_theta_dev, sizeof(double) * k * h->ntheta), "batch scratch");
+    HCK(hipMalloc(&h->b_dinv_dev, sizeof(double) * k * MINV_ELEMS * (size_t)h->ntc), "batch scratch");
+    HCK(hipMalloc(&h->b_alpha_dev, sizeof(double) * k * h->np), "batch scratch");
+    HCK(hipMalloc(&h->b_part_dev, sizeof(double) * k * (size_t)grad_contract_blocks(h->n) * h->ntheta), "batch scratch");
+    HCK(hipMalloc(&h->b_info_dev, sizeof(int) * 4 * k), "batch scratch");
+    HCK(hipHostMalloc(&h->b_grad_host, sizeof(double) * k * h->ntheta), "batch scratch");
+    HCK(hipHostMalloc(&h->b_out_host, sizeof(double) * 16 * k), "batch scratch");
+    HCK(hipHostMalloc(&h->b_theta_host, sizeof(double) * k * h->ntheta), "batch scratch");
+    h->batch_cap = b->count;
+  }
+  h->bbuf = *b;
+  return 0;
+}
+
+// what: 0 LML, 2 LML + gradient.  info_out[p]: 0, or the 1-based index of problem p's first bad pivot (its LML is -inf then).
+static int batch_internal(mi_gp_handle* h, int k, const double* thetas, int what, double* lml_out, double* grad_out, int* info_out) {
+  if (!h->have_data || h->batch_cap < 1) { snprintf(h->err, sizeof(h->err), "call mi_gp_set_data and mi_gp_set_batch first"); return -1; }
+  if (k < 1 || k > h->bbuf.count) { snprintf(h->err, sizeof(h->err), "batch of %d problems, buffers for %d", k, h->bbuf.count); return -1; }
+  if (what == 2 && (!h->bbuf.Z_dev || !h->bbuf.W_dev)) { snprintf(h->err, sizeof(h->err), "mi_gp_lml_grad_batch needs Z_dev and W_dev in mi_gp_set_batch"); return -1; }
+  HCK(hipSetDevice(h->device), "hipSetDevice");
+  for (int i = 0; i < k * h->ntheta; ++i) {
+    if (!std::isfinite(thetas[i])) { snprintf(h->err, sizeof(h->err), "theta[%d] of problem %d is not finite", i % h->ntheta, i / h->ntheta); return -1; }
+    h->b_theta_host[i] = thetas[i];
+  }
+  h->factored = h->have_kinv = h->have_u = false;  // the single-evaluation state of the handle is not touched, but K_dev may alias
+  // point the evaluation at the batch's arrays, run the ordinary enqueue code with blockIdx.z = problem, restore
+  const mi_gp_buffers buf0 = h->buf;
+  double *theta_dev0 = h->theta_dev, *dinv0 = h->dinv_dev, *alpha0 = h->alpha_dev, *part0 = h->part_dev, *grad0 = h->grad_host,
+         *out0 = h->out_host, *thost0 = h->theta_host;
+  int* info0 = h->info_dev;
+  h->buf.K_dev = h->bbuf.K_dev; h->buf.Z_dev = h->bbuf.Z_dev; h->buf.W_dev = h->bbuf.W_dev;
+  h->theta_dev = h->b_theta_dev; h->dinv_dev = h->b_dinv_dev; h->alpha_dev = h->b_alpha_dev; h->part_dev = h->b_part_dev;
+  h->grad_host = h->b_grad_host; h->out_host = h->b_out_host; h->theta_host = h->b_theta_host; h->info_dev = h->b_info_dev;
+  h->bt.nb = k;
+  h->bt.sK = h->bbuf.stride_k; h->bt.sZ = h->bt.sW = h->bbuf.stride_zw;
+  h->bt.sdinv = (long)MINV_ELEMS * h->ntc; h->bt.salpha = h->np;
+  h->bt.spart = (long)grad_contract_blocks(h->n) * h->ntheta;
+  h->bt.stheta = h->ntheta; h->bt.sinfo = 4; h->bt.sout = 16;
+  h->btp = &h->bt;
+  const int prof0 = h->prof_level;
+  h->prof_level = 0;
+  int r = run_evaluation(h, what);
+  if (r == 0) {
+    const hipError_t e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) r = hfail(h, e, "stream sync");
+  }
+  h->prof_level = prof0;
+  h->btp = nullptr;
+  h->bt = Batch();
+  h->buf = buf0;
+  h->theta_dev = theta_dev0; h->dinv_dev = dinv0; h->alpha_dev = alpha0; h->part_dev = part0; h->grad_host = grad0;
+  h->out_host = out0; h->theta_host = thost0; h->info_dev = info0;
+  if (r != 0) return r;
+  for (int p = 0; p < k; ++p) {
+    const int info = (int)h->b_out_host[16 * p + 3];
+    const bool ok = info == 0x7f7f7f7f;
+    if (info_out) info_out[p] = ok ? 0 : info;
+    lml_out[p] = ok ? h->b_out_host[16 * p] : -INFINITY;
+    if (grad_out)
+      for (int i = 0; i < h->ntheta; ++i) grad_out[(size_t)p * h->ntheta + i] = ok ? h->b_grad_host[(size_t)p * h->ntheta + i] : 0.0;
+  }
+  return 0;
+}
+
+extern "C" int mi_gp_lml_batch(mi_gp_handle* h, int k, const double* thetas, double* lml_out, int* info_out) {
+  if (!h || !thetas || !lml_out) return -1;
+  return batch_internal(h, k, thetas, 0, lml_out, nullptr, info_out);
+}
+
+extern "C" int mi_gp_lml_grad_batch(mi_gp_handle* h, int k, const double* thetas, double* lml_out, double* grad_out, int* info_out) {
+  if (!h || !thetas || !lml_out || !grad_out) return -1;
+  return batch_internal(h, k, thetas, 2, lml_out, grad_out, info_out);
 }
 
 // ---------------------------------------------------------------- conditional (K8)

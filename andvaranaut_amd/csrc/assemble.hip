@@ -53,9 +53,11 @@ constexpr int SROWS = AT / (256 / DCH);  // rows a thread stages per 64-row bloc
 // RESIDENT: the host guarantees nkern == 1 and d <= DCH (only the prefetching form is compiled), else only the general form.
 template <int KID_STATIC, bool RESIDENT>
 __global__ __launch_bounds__(256, (KID_STATIC >= 0 && KID_STATIC != KID_RATQUAD) ? 3 : 2) void assemble_kernel(
-    KernSpec spec, const double* __restrict__ theta, const double* __restrict__ X1, int n1, const double* __restrict__ X2, int n2,
-    double* __restrict__ K, long ldk, int rows_pad, int cols_pad, int sym, int noise_form, int diag_shift,
-    const double* __restrict__ extra_diag) {
+    KernSpec spec, const double* __restrict__ theta_in, const double* __restrict__ X1, int n1, const double* __restrict__ X2, int n2,
+    double* __restrict__ K_in, long ldk, int rows_pad, int cols_pad, int sym, int noise_form, int diag_shift,
+    const double* __restrict__ extra_diag, long sK, int stheta) {
+  const double* __restrict__ theta = theta_in + (long)blockIdx.z * stheta;  // batched evaluation: problem blockIdx.z
+  double* __restrict__ K = K_in + (long)blockIdx.z * sK;
   __shared__ __attribute__((aligned(16))) double Xi[AT * DLD];
   __shared__ __attribute__((aligned(16))) double Xj[AT * DLD];
   __shared__ double n2i[AT], n2j[AT];
@@ -236,7 +238,14 @@ __global__ __launch_bounds__(256, (KID_STATIC >= 0 && KID_STATIC != KID_RATQUAD)
 // rows [row0, row0+128) x cols [0, cols_pad): zero, except row row0 = y^T (first n entries)
 __global__ void set_yrows_kernel(double* __restrict__ K, long ldk, int row0, int cols_pad,
                                  const double* __restrict__ y, int n, int* __restrict__ info,
-                                 const double* __restrict__ theta_src, double* __restrict__ theta_dst, int ntheta) {
+                                 const double* __restrict__ theta_src, double* __restrict__ theta_dst, int ntheta, long sK,
+                                 int sinfo, int stheta) {
+  K += (long)blockIdx.z * sK;  // batched evaluation: problem blockIdx.z
+  if (info) info += (long)blockIdx.z * sinfo;
+  if (theta_src) {
+    theta_src += (long)blockIdx.z * stheta;
+    theta_dst += (long)blockIdx.z * stheta;
+  }
   // info (optional): the evaluation's bad-pivot word starts as "none" here (a memset less per evaluation)
   if (info && blockIdx.x == 0 && threadIdx.x == 0) info[0] = 0x7f7f7f7f;
   // theta (optional): this evaluation's hyper-parameters travel from the handle's pinned host buffer to the device copy
@@ -257,7 +266,12 @@ __global__ void set_yrows_kernel(double* __restrict__ K, long ldk, int row0, int
 // latency), partial sums combined in a fixed order (bit-reproducible).
 __global__ __launch_bounds__(256) void lml_reduce_kernel(const double* __restrict__ L, long ld,
                                                          const double* __restrict__ beta, int n,
-                                                         double* __restrict__ out, const int* __restrict__ info) {
+                                                         double* __restrict__ out, const int* __restrict__ info, long sK,
+                                                         int sout, int sinfo) {
+  L += (long)blockIdx.z * sK;  // batched evaluation: problem blockIdx.z
+  beta += (long)blockIdx.z * sK;
+  out += (long)blockIdx.z * sout;
+  if (info) info += (long)blockIdx.z * sinfo;
   __shared__ double s1[256], s2[256];
   double a = 0.0, b = 0.0;
   for (int i0 = threadIdx.x; i0 < n; i0 += 256 * 16) {
@@ -294,7 +308,7 @@ __global__ __launch_bounds__(256) void lml_reduce_kernel(const double* __restric
 
 hipError_t launch_assemble(const KernSpec& spec, const double* theta, const double* X1, int n1, const double* X2,
                            int n2, double* K, long ldk, int rows_pad, int cols_pad, int sym, int noise_form,
-                           hipStream_t stream, int diag_shift, const double* extra_diag) {
+                           hipStream_t stream, int diag_shift, const double* extra_diag, const Batch* bt) {
   int nblk;  // runs of up to TPW tiles of one tile row
   if (sym) {
     const int nt = rows_pad / AT, G = nt / TPW, rem = nt % TPW;
@@ -305,12 +319,15 @@ hipError_t launch_assemble(const KernSpec& spec, const double* theta, const doub
   const int ds = sym ? 0 : diag_shift;
   const double* ed = sym ? extra_diag : nullptr;
   const bool resident = spec.nkern == 1 && spec.d <= DCH;
+  const dim3 grid(nblk, 1, bt ? bt->nb : 1);
+  const long sK = bt ? bt->sK : 0;
+  const int sth = bt ? bt->stheta : 0;
 #define MIGP_ASM(KID)                                                                                                              \
   do {                                                                                                                             \
     if (resident)                                                                                                                  \
-      assemble_kernel<KID, true><<<nblk, 256, 0, stream>>>(spec, theta, X1, n1, X2, n2, K, ldk, rows_pad, cols_pad, sym, noise_form, ds, ed);  \
+      assemble_kernel<KID, true><<<grid, 256, 0, stream>>>(spec, theta, X1, n1, X2, n2, K, ldk, rows_pad, cols_pad, sym, noise_form, ds, ed, sK, sth);  \
     else                                                                                                                           \
-      assemble_kernel<KID, false><<<nblk, 256, 0, stream>>>(spec, theta, X1, n1, X2, n2, K, ldk, rows_pad, cols_pad, sym, noise_form, ds, ed); \
+      assemble_kernel<KID, false><<<grid, 256, 0, stream>>>(spec, theta, X1, n1, X2, n2, K, ldk, rows_pad, cols_pad, sym, noise_form, ds, ed, sK, sth); \
   } while (0)
   if (spec.nkern != 1) MIGP_ASM(-1);
   else if (spec.kid[0] == KID_RBF) MIGP_ASM(KID_RBF);
@@ -323,17 +340,19 @@ hipError_t launch_assemble(const KernSpec& spec, const double* theta, const doub
 }
 
 hipError_t launch_set_yrows(double* K, long ldk, int row0, int cols_pad, const double* y, int n, hipStream_t stream,
-                            int* info, const double* theta_src, double* theta_dst, int ntheta) {
+                            int* info, const double* theta_src, double* theta_dst, int ntheta, const Batch* bt) {
   const long total = 128L * cols_pad;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  set_yrows_kernel<<<blocks, 256, 0, stream>>>(K, ldk, row0, cols_pad, y, n, info, theta_src, theta_dst, ntheta);
+  set_yrows_kernel<<<dim3(blocks, 1, bt ? bt->nb : 1), 256, 0, stream>>>(K, ldk, row0, cols_pad, y, n, info, theta_src, theta_dst, ntheta,
+                                                                         bt ? bt->sK : 0, bt ? bt->sinfo : 0, bt ? bt->stheta : 0);
   return hipGetLastError();
 }
 
 hipError_t launch_lml_reduce(const double* L, long ld, const double* beta, int n, double* out, hipStream_t stream,
-                             const int* info) {
-  lml_reduce_kernel<<<1, 256, 0, stream>>>(L, ld, beta, n, out, info);
+                             const int* info, const Batch* bt) {
+  lml_reduce_kernel<<<dim3(1, 1, bt ? bt->nb : 1), 256, 0, stream>>>(L, ld, beta, n, out, info, bt ? bt->sK : 0, bt ? bt->sout : 0,
+                                                                     bt ? bt->sinfo : 0);
   return hipGetLastError();
 }
 

@@ -204,9 +204,11 @@ __global__ __launch_bounds__(vb::NT_B, 2) void gemm_f64_kernel_b(GemmParams p) {
   else if (p.kmode == 3) kbeg = i0;
   else if (p.kmode == 4) kend = j0 + TILE;
 
-  const double* A = p.A + (long)blockIdx.z * p.strideA;
-  const double* B = p.B + (long)blockIdx.z * p.strideB;
-  double* C = p.C + (long)blockIdx.z * p.strideC;
+  // blockIdx.z = z1 + batch1 * z2 (two-level batch: nodes of a triangular-inverse level x problems of a batched evaluation)
+  const long z1 = p.batch1 > 0 ? (long)(blockIdx.z % p.batch1) : (long)blockIdx.z, z2 = p.batch1 > 0 ? (long)(blockIdx.z / p.batch1) : 0;
+  const double* A = p.A + z1 * p.strideA + z2 * p.strideA2;
+  const double* B = p.B + z1 * p.strideB + z2 * p.strideB2;
+  double* C = p.C + z1 * p.strideC + z2 * p.strideC2;
 
   double4_t acc[4][4];
 #pragma unroll
@@ -464,9 +466,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel_s(GemmParams p) {
   else if (p.kmode == 4) kend = j0 + TS;
   kbeg &= ~(BKS - 1);
 
-  const double* A = p.A + (long)blockIdx.z * p.strideA;
-  const double* B = p.B + (long)blockIdx.z * p.strideB;
-  double* C = p.C + (long)blockIdx.z * p.strideC;
+  // blockIdx.z = z1 + batch1 * z2 (two-level batch: nodes of a triangular-inverse level x problems of a batched evaluation)
+  const long z1 = p.batch1 > 0 ? (long)(blockIdx.z % p.batch1) : (long)blockIdx.z, z2 = p.batch1 > 0 ? (long)(blockIdx.z / p.batch1) : 0;
+  const double* A = p.A + z1 * p.strideA + z2 * p.strideA2;
+  const double* B = p.B + z1 * p.strideB + z2 * p.strideB2;
+  double* C = p.C + z1 * p.strideC + z2 * p.strideC2;
 
   double4_t acc[2][2];
 #pragma unroll

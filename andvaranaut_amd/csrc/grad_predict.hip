@@ -17,8 +17,8 @@ constexpr int GT = 64;  // contraction tile
 constexpr int GDCH = 32;
 constexpr int GDLD = GDCH + 1;
 
-__global__ void set_identity_blocks_kernel(double* __restrict__ U, long ld) {
-  double* blk = U + (long)blockIdx.x * 128 * ld + (long)blockIdx.x * 128;
+__global__ void set_identity_blocks_kernel(double* __restrict__ U, long ld, long sZ) {
+  double* blk = U + (long)blockIdx.z * sZ + (long)blockIdx.x * 128 * ld + (long)blockIdx.x * 128;
   for (int e = threadIdx.x; e < 128 * 128; e += blockDim.x) {
     const int r = e >> 7, c = e & 127;
     blk[(long)r * ld + c] = (r == c) ? 1.0 : 0.0;
@@ -29,7 +29,10 @@ __global__ void set_identity_blocks_kernel(double* __restrict__ U, long ld) {
 // beyond n hold the padding (identity diagonal / zeros) and beta is zero there by construction.
 __global__ __launch_bounds__(256) void trmv_upper_kernel(const double* __restrict__ U, long ld,
                                                          const double* __restrict__ beta, int n,
-                                                         double* __restrict__ alpha) {
+                                                         double* __restrict__ alpha, long sZ, long sK, long salpha) {
+  U += (long)blockIdx.z * sZ;  // batched evaluation: problem blockIdx.z
+  beta += (long)blockIdx.z * sK;
+  alpha += (long)blockIdx.z * salpha;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= n) return;
@@ -115,7 +118,12 @@ __global__ __launch_bounds__(256) void grad_contract_kernel(KernSpec spec, const
                                                             const double* __restrict__ W, long ldw,
                                                             const double* __restrict__ alpha_v,
                                                             double* __restrict__ part, int rect_tw, int tj0,
-                                                            long wrow0, long wcol0) {
+                                                            long wrow0, long wcol0, int stheta, long sW, long salpha,
+                                                            long spart) {
+  theta += (long)blockIdx.z * stheta;  // batched evaluation: problem blockIdx.z
+  W += (long)blockIdx.z * sW;
+  alpha_v += (long)blockIdx.z * salpha;
+  part += (long)blockIdx.z * spart;
   __shared__ double Xi[GT * GDLD];
   __shared__ double Xj[GT * GDLD];
   __shared__ double red[256];
@@ -544,7 +552,10 @@ __global__ __launch_bounds__(256) void grad_x_kernel(KernSpec spec, const double
 
 // grad[p] = sum_b part[b][p] in a fixed order (the weights already are 1 below the diagonal and 1/2
 // on it, which is 1/2 sum over the full symmetric matrix).
-__global__ void grad_final_kernel(const double* __restrict__ part, int nblk, int P, double* __restrict__ grad) {
+__global__ void grad_final_kernel(const double* __restrict__ part, int nblk, int P, double* __restrict__ grad, long spart,
+                                  int sgrad) {
+  part += (long)blockIdx.z * spart;  // batched evaluation: problem blockIdx.z
+  grad += (long)blockIdx.z * sgrad;
   const int p = blockIdx.x;
   __shared__ double red[256];
   double s = 0.0;
@@ -583,13 +594,15 @@ __global__ __launch_bounds__(256) void predict_reduce_kernel(const double* __res
   }
 }
 
-hipError_t launch_set_identity_blocks(double* U, long ld, int nblocks, hipStream_t stream) {
-  set_identity_blocks_kernel<<<nblocks, 256, 0, stream>>>(U, ld);
+hipError_t launch_set_identity_blocks(double* U, long ld, int nblocks, hipStream_t stream, const Batch* bt) {
+  set_identity_blocks_kernel<<<dim3(nblocks, 1, bt ? bt->nb : 1), 256, 0, stream>>>(U, ld, bt ? bt->sZ : 0);
   return hipGetLastError();
 }
 
-hipError_t launch_trmv_upper(const double* U, long ld, const double* beta, int n, double* alpha, hipStream_t stream) {
-  trmv_upper_kernel<<<(n + 3) / 4, 256, 0, stream>>>(U, ld, beta, n, alpha);
+hipError_t launch_trmv_upper(const double* U, long ld, const double* beta, int n, double* alpha, hipStream_t stream,
+                             const Batch* bt) {
+  trmv_upper_kernel<<<dim3((n + 3) / 4, 1, bt ? bt->nb : 1), 256, 0, stream>>>(U, ld, beta, n, alpha, bt ? bt->sZ : 0, bt ? bt->sK : 0,
+                                                                               bt ? bt->salpha : 0);
   return hipGetLastError();
 }
 
@@ -599,19 +612,22 @@ int grad_contract_blocks(int n) {
 }
 
 hipError_t launch_grad_contract(const KernSpec& spec, const double* theta, const double* X, int n, const double* W,
-                                long ldw, const double* alpha, double* part, double* grad, hipStream_t stream) {
+                                long ldw, const double* alpha, double* part, double* grad, hipStream_t stream, const Batch* bt) {
   const int nblk = grad_contract_blocks(n);
   const int P = spec.nkern * spec.d + 2 * spec.nkern + 2;
+  const dim3 grid(nblk, 1, bt ? bt->nb : 1);
+  const int sth = bt ? bt->stheta : 0;
+  const long sW = bt ? bt->sW : 0, sal = bt ? bt->salpha : 0, sp = bt ? bt->spart : 0;
   switch (spec.nkern) {
-    case 1: grad_contract_kernel<1><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, 0, 0, 0, 0); break;
-    case 2: grad_contract_kernel<2><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, 0, 0, 0, 0); break;
-    case 3: grad_contract_kernel<3><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, 0, 0, 0, 0); break;
-    case 4: grad_contract_kernel<4><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, 0, 0, 0, 0); break;
-    default: grad_contract_kernel<8><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, 0, 0, 0, 0); break;
+    case 1: grad_contract_kernel<1><<<grid, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, 0, 0, 0, 0, sth, sW, sal, sp); break;
+    case 2: grad_contract_kernel<2><<<grid, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, 0, 0, 0, 0, sth, sW, sal, sp); break;
+    case 3: grad_contract_kernel<3><<<grid, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, 0, 0, 0, 0, sth, sW, sal, sp); break;
+    case 4: grad_contract_kernel<4><<<grid, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, 0, 0, 0, 0, sth, sW, sal, sp); break;
+    default: grad_contract_kernel<8><<<grid, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, 0, 0, 0, 0, sth, sW, sal, sp); break;
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  grad_final_kernel<<<P, 256, 0, stream>>>(part, nblk, P, grad);
+  grad_final_kernel<<<dim3(P, 1, bt ? bt->nb : 1), 256, 0, stream>>>(part, nblk, P, grad, sp, sth);
   return hipGetLastError();
 }
 
@@ -632,15 +648,15 @@ hipError_t launch_grad_contract_slab(const KernSpec& spec, const double* theta, 
   if (tw <= 0) return hipMemsetAsync(grad, 0, sizeof(double) * P, stream);
   const int nblk = (nt - tj0) * tw;
   switch (spec.nkern) {
-    case 1: grad_contract_kernel<1><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, tw, tj0, row0, col0); break;
-    case 2: grad_contract_kernel<2><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, tw, tj0, row0, col0); break;
-    case 3: grad_contract_kernel<3><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, tw, tj0, row0, col0); break;
-    case 4: grad_contract_kernel<4><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, tw, tj0, row0, col0); break;
-    default: grad_contract_kernel<8><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, tw, tj0, row0, col0); break;
+    case 1: grad_contract_kernel<1><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, tw, tj0, row0, col0, 0, 0, 0, 0); break;
+    case 2: grad_contract_kernel<2><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, tw, tj0, row0, col0, 0, 0, 0, 0); break;
+    case 3: grad_contract_kernel<3><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, tw, tj0, row0, col0, 0, 0, 0, 0); break;
+    case 4: grad_contract_kernel<4><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, tw, tj0, row0, col0, 0, 0, 0, 0); break;
+    default: grad_contract_kernel<8><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, tw, tj0, row0, col0, 0, 0, 0, 0); break;
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  grad_final_kernel<<<P, 256, 0, stream>>>(part, nblk, P, grad);
+  grad_final_kernel<<<P, 256, 0, stream>>>(part, nblk, P, grad, 0, 0);
   return hipGetLastError();
 }
 

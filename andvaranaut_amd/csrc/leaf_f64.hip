@@ -651,10 +651,12 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
 
 __global__ __launch_bounds__(256, 1) void potrf_leaf128_kernel(double* __restrict__ Ablk, long lda,
                                                                 double* __restrict__ minv, int col0,
-                                                                int* __restrict__ info, double* yrow) {
+                                                                int* __restrict__ info, double* yrow, long sA, long sminv,
+                                                                int sinfo) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   __builtin_amdgcn_s_setprio(3);  // the leaf is the panel chain: win the issue arbitration against bulk GEMM waves on its CU
-  potrf_leaf128_body(Ablk, lda, minv, col0, info, smem, yrow);
+  const long z = blockIdx.x;  // batched evaluation: one workgroup per problem
+  potrf_leaf128_body(Ablk + z * sA, lda, minv + z * sminv, col0, info + z * sinfo, smem, yrow ? yrow + z * sA : nullptr);
 }
 
 // X * L^T = B in place on B (m x 128, leading dimension ldb even, m multiple of 16 RG) as X = B * M^T with M = L^-1
@@ -746,9 +748,11 @@ __device__ __forceinline__ void trsm_strip128_body(const double* __restrict__ mi
 // one launch serves `gridDim.y` independent (M, B) pairs: M at minv + y * 16384, B at B + y * strideB
 template <int RG>
 __global__ __launch_bounds__(256) void trsm_strip128_kernel(const double* __restrict__ minv, double* __restrict__ B, long ldb,
-                                                             long strideB) {
+                                                             long strideB, long sminv2, long sB2) {
   __builtin_amdgcn_s_setprio(3);
-  trsm_strip128_body<RG>(minv + (long)blockIdx.y * (LEAF * LEAF), B + (long)blockIdx.y * strideB, ldb, blockIdx.x);
+  // blockIdx.z: problem of a batched evaluation (second batch level)
+  trsm_strip128_body<RG>(minv + (long)blockIdx.y * (LEAF * LEAF) + (long)blockIdx.z * sminv2,
+                         B + (long)blockIdx.y * strideB + (long)blockIdx.z * sB2, ldb, blockIdx.x);
 }
 
 constexpr size_t LEAF_LDS_BYTES = sizeof(double) * (LEAF_ELEMS + 2 * SB * SB + LEAF + 3);
@@ -759,25 +763,29 @@ hipError_t leaf_enable_lds() {
   return e;
 }
 
-hipError_t launch_potrf_leaf128(double* Ablk, long lda, double* minv, int col0, int* info, hipStream_t stream, double* yrow) {
-  potrf_leaf128_kernel<<<1, 256, LEAF_LDS_BYTES, stream>>>(Ablk, lda, minv, col0, info, yrow);
+hipError_t launch_potrf_leaf128(double* Ablk, long lda, double* minv, int col0, int* info, hipStream_t stream, double* yrow,
+                                const Batch* bt) {
+  potrf_leaf128_kernel<<<bt ? bt->nb : 1, 256, LEAF_LDS_BYTES, stream>>>(Ablk, lda, minv, col0, info, yrow, bt ? bt->sK : 0,
+                                                                        bt ? bt->sdinv : 0, bt ? bt->sinfo : 0);
   return hipGetLastError();
 }
 
 // rows per workgroup by panel height: 16 while one round of workgroups covers the panel (lowest latency), 32 / 64 for
 // tall panels (the wave's tiles of M are reused, 1/2 and 1/4 of the operand traffic); m is a multiple of 64 or of 16
 hipError_t launch_trsm_strip128_batched(const double* minv, double* B, long ldb, long strideB, int m, int batch,
-                                        hipStream_t stream) {
+                                        hipStream_t stream, const Batch* bt, long sB2) {
   if (m <= 0 || batch <= 0) return hipSuccess;
-  const long rows = (long)m * batch;
-  if (rows > 8192 && m % 64 == 0) trsm_strip128_kernel<4><<<dim3(m / 64, batch), 256, 0, stream>>>(minv, B, ldb, strideB);
-  else if (rows > 4096 && m % 32 == 0) trsm_strip128_kernel<2><<<dim3(m / 32, batch), 256, 0, stream>>>(minv, B, ldb, strideB);
-  else trsm_strip128_kernel<1><<<dim3(m / 16, batch), 256, 0, stream>>>(minv, B, ldb, strideB);
+  const int nb = bt ? bt->nb : 1;
+  const long sm2 = bt ? bt->sdinv : 0;
+  const long rows = (long)m * batch * nb;
+  if (rows > 8192 && m % 64 == 0) trsm_strip128_kernel<4><<<dim3(m / 64, batch, nb), 256, 0, stream>>>(minv, B, ldb, strideB, sm2, sB2);
+  else if (rows > 4096 && m % 32 == 0) trsm_strip128_kernel<2><<<dim3(m / 32, batch, nb), 256, 0, stream>>>(minv, B, ldb, strideB, sm2, sB2);
+  else trsm_strip128_kernel<1><<<dim3(m / 16, batch, nb), 256, 0, stream>>>(minv, B, ldb, strideB, sm2, sB2);
   return hipGetLastError();
 }
 
-hipError_t launch_trsm_strip128(const double* minv, double* B, long ldb, int m, hipStream_t stream) {
-  return launch_trsm_strip128_batched(minv, B, ldb, 0, m, 1, stream);
+hipError_t launch_trsm_strip128(const double* minv, double* B, long ldb, int m, hipStream_t stream, const Batch* bt, long sB2) {
+  return launch_trsm_strip128_batched(minv, B, ldb, 0, m, 1, stream, bt, sB2);
 }
 
 }  // namespace migp

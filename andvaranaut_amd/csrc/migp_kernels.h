@@ -4,6 +4,20 @@
 
 namespace migp {
 
+// Batched evaluation (mi_gp_lml_batch / mi_gp_lml_grad_batch): nb covariances of the SAME inputs, one theta each, factorised
+// in lockstep -- every launch carries blockIdx.z = problem, so the latency-bound panel chain of one problem runs beside the
+// chains of the others.  Strides are in elements; nb = 1 with zero strides is the ordinary single evaluation.
+struct Batch {
+  int nb = 1;
+  long sK = 0, sZ = 0, sW = 0;  // between consecutive problems' K / Z (U = L^-T) / W (K^-1) matrices
+  long sdinv = 0;               // ... leaf inverses (ntc * MINV_ELEMS doubles)
+  long salpha = 0;              // ... alpha vectors (np doubles)
+  long spart = 0;               // ... gradient partial sums
+  int stheta = 0;               // ... theta vectors (device copy, pinned host source, pinned gradient)
+  int sinfo = 0;                // ... bad-pivot words (ints)
+  int sout = 0;                 // ... scalar records in pinned host memory (doubles)
+};
+
 // ---------------------------------------------------------------- gemm_f64.hip
 // C[mt*128 x nt*128] = beta*C + alpha * op(A) * op(B), all fp64 row-major with leading dimensions.
 struct GemmParams {
@@ -12,6 +26,10 @@ struct GemmParams {
   double* C;
   long lda, ldb, ldc;
   long strideA, strideB, strideC;  // batch strides in elements (blockIdx.z)
+  // two-level batch (node-batched launches of the triangular inverse for nb problems): blockIdx.z = z1 + batch1 * z2, level-2
+  // strides apply to z2; batch1 = 0: one level
+  int batch1 = 0;
+  long strideA2 = 0, strideB2 = 0, strideC2 = 0;
   int mt, nt;                      // output tiles (128 x 128) in rows / columns
   int k;                           // contraction length, multiple of 32
   int tri;                         // 1: only tiles with tj <= min(ti, nt-1)  (SYRK / trapezoid)
@@ -62,12 +80,14 @@ constexpr int MINV_ELEMS = 128 * 128;  // doubles per leaf inverse
 // never read); *info gets atomicMin(col0 + j + 1) on a bad pivot.
 // yrow (optional): row 0 of the 128-row block right below Ablk, solved in place against the leaf's inverse (beta = y M^T)
 hipError_t launch_potrf_leaf128(double* Ablk, long lda, double* minv, int col0, int* info, hipStream_t stream,
-                                double* yrow = nullptr);
+                                double* yrow = nullptr, const Batch* bt = nullptr);
 // X * L^T = B in place on the m x 128 panel B (m multiple of 16, ldb even) as X = B * M^T with the leaf's inverse M.
-hipError_t launch_trsm_strip128(const double* minv, double* B, long ldb, int m, hipStream_t stream);
+hipError_t launch_trsm_strip128(const double* minv, double* B, long ldb, int m, hipStream_t stream, const Batch* bt = nullptr,
+                                long sB2 = 0);
 // batched form: pair b uses minv + b * MINV_ELEMS and B + b * strideB (m rows each)
+// bt (optional): a second batch level over problems (blockIdx.z): minv + z * bt->sdinv, B + z * sB2
 hipError_t launch_trsm_strip128_batched(const double* minv, double* B, long ldb, long strideB, int m, int batch,
-                                        hipStream_t stream);
+                                        hipStream_t stream, const Batch* bt = nullptr, long sB2 = 0);
 
 // ---------------------------------------------------------------- assemble.hip
 enum { KID_RBF = 0, KID_MATERN52 = 1, KID_MATERN32 = 2, KID_EXPONENTIAL = 3, KID_RATQUAD = 4 };
@@ -83,25 +103,30 @@ struct KernSpec {
 // sym=0: full K(X1,X2), zeros in the padding.  noise_form: 0 marginal, 1 conditional, 2 explicit.
 hipError_t launch_assemble(const KernSpec& spec, const double* theta, const double* X1, int n1, const double* X2,
                            int n2, double* K, long ldk, int rows_pad, int cols_pad, int sym, int noise_form,
-                           hipStream_t stream, int diag_shift = -2147483647 - 1, const double* extra_diag = nullptr);
+                           hipStream_t stream, int diag_shift = -2147483647 - 1, const double* extra_diag = nullptr,
+                           const Batch* bt = nullptr);
 // diag_shift (sym=0 only): local element (i, j) is on the global diagonal when i + diag_shift == j
 // (rectangular blocks of a distributed covariance); the default means "no diagonal" (cross-covariance).
 // info (optional): reset to 0x7f7f7f7f ("no bad pivot") by the same launch
 hipError_t launch_set_yrows(double* K, long ldk, int row0, int cols_pad, const double* y, int n, hipStream_t stream,
-                            int* info = nullptr, const double* theta_src = nullptr, double* theta_dst = nullptr, int ntheta = 0);
+                            int* info = nullptr, const double* theta_src = nullptr, double* theta_dst = nullptr, int ntheta = 0,
+                            const Batch* bt = nullptr);
 // info (optional): its first word is forwarded as out[3]
 hipError_t launch_lml_reduce(const double* L, long ld, const double* beta, int n, double* out, hipStream_t stream,
-                             const int* info = nullptr);
+                             const int* info = nullptr, const Batch* bt = nullptr);
 
 // ---------------------------------------------------------------- grad_predict.hip
-hipError_t launch_set_identity_blocks(double* U, long ld, int nblocks, hipStream_t stream);
-hipError_t launch_trmv_upper(const double* U, long ld, const double* beta, int n, double* alpha, hipStream_t stream);
+hipError_t launch_set_identity_blocks(double* U, long ld, int nblocks, hipStream_t stream, const Batch* bt = nullptr);
+// bt: U + z * sZ, beta + z * sK (beta is a row of the factor's matrix), alpha + z * salpha
+hipError_t launch_trmv_upper(const double* U, long ld, const double* beta, int n, double* alpha, hipStream_t stream,
+                             const Batch* bt = nullptr);
 // out = U^T x (= L^-1 x for U = L^-T)
 hipError_t launch_trmv_upper_t(const double* U, long ld, const double* x, int n, double* out, hipStream_t stream);
 int grad_contract_blocks(int n);
 // part: [grad_contract_blocks(n)][ntheta] scratch; grad: [ntheta] (natural parameters, C-ABI order)
 hipError_t launch_grad_contract(const KernSpec& spec, const double* theta, const double* X, int n, const double* W,
-                                long ldw, const double* alpha, double* part, double* grad, hipStream_t stream);
+                                long ldw, const double* alpha, double* part, double* grad, hipStream_t stream,
+                                const Batch* bt = nullptr);
 // column slab [col0, col0+cols) of the lower triangle (distributed K^-1): W points at element (row0, col0), row0 <= col0
 int grad_contract_slab_blocks(int n, int col0, int cols);
 hipError_t launch_grad_contract_slab(const KernSpec& spec, const double* theta, const double* X, int n, const double* W,

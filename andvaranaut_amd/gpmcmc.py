@@ -461,13 +461,16 @@ class GPMCMC(ConsumersMixin):
 
     def __sample(self, model, gp, x, y, xin, yin, iwgp=False, cwgp=False, draws=1000, tune=1000, chains=None,
                  cores=None, target_accept=0.8, random_seed=None, max_treedepth=10, progressbar=False, devices=None,
-                 chains_per_device=None, **_):
+                 chains_per_device=None, batched=None, **_):
         """pm.sample(**kwargs) of gpmcmc.py:351: independent NUTS chains, one device handle per concurrent chain
         (one chain per GPU when several are visible: SURVEY.md section 8e).  Chains that share a GPU run on up to
         ``chains_per_device`` handles at once (default: up to 3 while their buffers fit): below N ~ 10^4 one evaluation
         is bound by the serial panel chain and leaves most of the chip idle -- three concurrent handles on one MI355X
         deliver 2.7x the evaluations/s at N=1024, 2.2x at N=4096, 1.25x at N=8192 (tools/dev_concurrent.py), and every
-        chain's draws are the same as when it runs alone (evaluations are deterministic per handle)."""
+        chain's draws are the same as when it runs alone (evaluations are deterministic per handle).
+        Round 4: without warp parameters (and unless ``chains_per_device`` / ``batched=False`` ask for lanes) the chains of a
+        device share ONE handle and meet in one batched evaluation per leapfrog step (blockIdx.z = chain): N=4096 LML
+        1440 evaluations/s with eight chains against 1000 with three handles, N=2048 LML + gradient 2800 against 1860."""
         import torch
 
         chains = max(2, min(4, os.cpu_count() or 2)) if chains is None else int(chains)
@@ -526,8 +529,42 @@ class GPMCMC(ConsumersMixin):
             except Exception as e:  # noqa: BLE001 - reported by the caller's thread
                 errors.append(e)
 
+        # Batched mode (round 4): the chains of a device share ONE handle and meet once per leapfrog step in ONE batched
+        # device call (batching.BatchedEvaluator -> mi_gp_lml_grad_batch, blockIdx.z = chain) -- without warp parameters
+        # only: warped chains evaluate different DATA, not just different theta.  Same draws as the unbatched schedule.
+        def run_batched(dev, cs, h_existing):
+            try:
+                from .batching import BatchedEvaluator
+
+                h = h_existing or MiGP(xin, yin, self.kernel, device=dev)
+                ev = BatchedEvaluator(h.lml_grad_batch, len(cs))
+
+                def one(c):
+                    try:
+                        f = lambda q: model.logp_dlogp(q, ev.evaluate)  # noqa: E731
+                        results[c] = sample_chain(f, model.initial_point(), draws=draws, tune=tune, target_accept=target_accept,
+                                                  max_treedepth=max_treedepth, seed=seeds[c], progressbar=progressbar and c == 0)
+                    except Exception as e:  # noqa: BLE001
+                        errors.append(e)
+                    finally:
+                        ev.leave()
+
+                ts = [threading.Thread(target=one, args=(c,)) for c in cs]
+                for t in ts:
+                    t.start()
+                for t in ts:
+                    t.join()
+                if h_existing is None:
+                    h.close()
+            except Exception as e:  # noqa: BLE001
+                errors.append(e)
+
         threads = []
+        use_batch = (batched if batched is not None else True) and not (iwgp or cwgp)
         for dev, cs in by_dev.items():
+            if use_batch and len(cs) > 1 and chains_per_device is None:
+                threads.append(threading.Thread(target=run_batched, args=(dev, cs, gp if dev == self.device else None)))
+                continue
             k = lanes_for(dev, len(cs))
             for lane in range(k):
                 mine = cs[lane::k]

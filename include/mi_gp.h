@@ -75,6 +75,26 @@ int mi_gp_lml_parts(mi_gp_handle* h, double* logdet_out, double* quad_out);
  * pm.find_MAP (gpmcmc.py:332,345,357) and pm.sample / NUTS (gpmcmc.py:351) call per step. */
 int mi_gp_lml_grad(mi_gp_handle* h, const double* theta_host, double* lml_out, double* grad_out);
 
+/* Batched evaluation: `count` covariances of the SAME inputs, one theta each, factorised in lockstep (every kernel launch
+ * of the evaluation carries blockIdx.z = problem).  One evaluation below N ~ 10^4 is bound by its serial panel chain and
+ * leaves most of the chip idle; the reference evaluates the same data at several theta at once in its MAP restarts
+ * (gpmcmc.py:328-343) and in the chains of pm.sample (gpmcmc.py:351).  Buffers (PyTorch tensors, borrowed): problem p uses
+ * K_dev + p * stride_k ((np + 128) x lda each, the lda of mi_gp_set_data) and, for the gradient, Z_dev / W_dev +
+ * p * stride_zw (np x lda each); strides in elements, even.  Results are those of mi_gp_lml / mi_gp_lml_grad at the same
+ * theta (same arithmetic per element).  info_out[p] (optional): 0, or the 1-based index of problem p's first non-positive
+ * pivot (lml_out[p] = -inf, its gradient 0).  The handle's single-evaluation state (factor, K^-1) is invalidated. */
+typedef struct mi_gp_batch_buffers {
+  double* K_dev;
+  double* Z_dev; /* may be NULL: mi_gp_lml_batch only */
+  double* W_dev; /* may be NULL: mi_gp_lml_batch only */
+  long stride_k;
+  long stride_zw;
+  int count;
+} mi_gp_batch_buffers;
+int mi_gp_set_batch(mi_gp_handle* h, const mi_gp_batch_buffers* buffers);
+int mi_gp_lml_batch(mi_gp_handle* h, int k, const double* thetas_host, double* lml_out, int* info_out);
+int mi_gp_lml_grad_batch(mi_gp_handle* h, int k, const double* thetas_host, double* lml_out, double* grads_out, int* info_out);
+
 /* Data-side gradients at the theta of the last successful mi_gp_lml_grad (K^-1 and alpha still resident):
  *   mi_gp_alpha  : alpha = K^-1 y (n doubles to the host); dLML/dy = -alpha
  *   mi_gp_grad_x : dLML/dX (n x d row-major, device), dLML/dx_im = sum_j (alpha_i alpha_j - Kinv_ij) dK_ij/dx_im

@@ -79,6 +79,20 @@ def test_chains_sharing_a_gpu_run_concurrently_with_identical_draws():
     assert np.array_equal(out[1].sample_stats["lp"], out[3].sample_stats["lp"])
 
 
+def test_batched_chains_have_the_draws_of_the_unbatched_schedule():
+    # default since round 4: the chains of a device share ONE handle and meet once per leapfrog step in one batched
+    # evaluation (blockIdx.z = chain, mi_gp_lml_grad_batch); a batched evaluation returns the bits of the one-at-a-time
+    # entry point, so the draws are those of the back-to-back schedule (gpmcmc.py:351)
+    out = {}
+    for mode in ("batched", "serial"):
+        g, _ = _tutorial_gp(kernel="RBF", noise=True, n=40, seed=3)
+        kw = {} if mode == "batched" else {"chains_per_device": 1}
+        out[mode] = g.fit(method="mcmc_mean", return_data=True, draws=25, tune=25, chains=4, random_seed=11, **kw)
+    for name in ("l", "kv", "gv"):
+        assert np.array_equal(out["batched"].posterior[name], out["serial"].posterior[name]), name
+    assert np.array_equal(out["batched"].sample_stats["lp"], out["serial"].sample_stats["lp"])
+
+
 def test_mcmc_modes_short_chains():
     g, fun = _tutorial_gp(kernel="RBF", noise=True, n=40, seed=3)
     data = g.fit(method="mcmc_mean", return_data=True, draws=60, tune=60, chains=2, random_seed=1)

@@ -62,3 +62,25 @@ def test_lml_grad_n8192_matches_oracle():
     err = np.abs(g - gref).max() / np.abs(gref).max()
     print(f"N=8192 RBF gradient: max component error {err:.3e} of the largest component")
     assert err <= 1e-8, (g, gref)
+
+
+def test_predict_at_n8192_through_both_routes_matches_the_oracle():
+    """K8 (gpmcmc.py:588-598, 766-778) above the sizes of tests/test_gpu_grad_predict.py: posterior mean and variance at
+    N = 8192, M = 512 through the blocked triangular solve (mi_gp_predict) AND through U = L^-T with one triangular-k GEMM
+    (mi_gp_predict_u, the route large BO sweeps take) against oracle.predict.  N = 16384, M = 1000:
+    profiles/r04_fullsize_parity.json (tools/fullsize_parity.py predict)."""
+    from andvaranaut_amd import MiGP
+    from bench import reference_theta, synth_problem
+    from oracle import gp_oracle as orc
+
+    N, d, M = 8192, 8, 512
+    X, y = synth_problem(N, d, seed=0)
+    theta = reference_theta(d)
+    Xn = np.random.default_rng(3).random((M, d))
+    rmu, rvar = orc.predict(X, y, Xn, ["RBF"], [], theta)
+    gp = MiGP(X, y, "RBF")
+    for via in (False, True):
+        mu, var = gp.predict(theta, Xn, via_inverse=via)
+        assert np.max(np.abs(mu - rmu)) <= 1e-8 * np.abs(rmu).max(), (via, np.max(np.abs(mu - rmu)))
+        assert np.max(np.abs(var - rvar) / rvar) <= 1e-6, (via, np.max(np.abs(var - rvar) / rvar))
+    gp.close()

@@ -470,3 +470,61 @@ def test_gauss_hermite_reversion_matches_the_per_point_loop():
                     ref = loop(g, x, mu, var, normvar, deg, EI, EIopt)
                     assert np.allclose(got[0], ref[0], rtol=1e-13, atol=1e-15), (normvar, deg, EI, EIopt)
                     assert np.allclose(got[1], ref[1], rtol=1e-11, atol=1e-14), (normvar, deg, EI, EIopt)
+
+
+def test_batched_evaluator_rendezvous_serves_every_client_its_own_row():
+    """andvaranaut_amd/batching.py: K host threads (the NUTS chains of one GPU, gpmcmc.py:351) meet in one batched call per
+    round; clients that finish early leave and the others go on in smaller batches; a failing batch raises in every client."""
+    import threading
+
+    from andvaranaut_amd.batching import BatchedEvaluator
+
+    sizes = []
+
+    def batch_fn(th):
+        sizes.append(len(th))
+        return th.sum(axis=1), 2.0 * th
+
+    K = 5
+    ev = BatchedEvaluator(batch_fn, K)
+    got = {}
+
+    def client(c):
+        try:
+            for step in range(3 + c):  # clients leave at different times
+                th = np.array([c, step, 1.0])
+                v, g = ev.evaluate(th)
+                assert v == th.sum() and np.array_equal(g, 2.0 * th)
+                got[(c, step)] = v
+        finally:
+            ev.leave()
+
+    ts = [threading.Thread(target=client, args=(c,)) for c in range(K)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=30)
+    assert not any(t.is_alive() for t in ts)
+    assert len(got) == sum(3 + c for c in range(K)) and ev.evaluations == len(got)
+    assert sizes[:3] == [5, 5, 5] and sizes[-1] == 1 and sorted(set(sizes)) == [1, 2, 3, 4, 5]
+
+    def bad(th):
+        raise ValueError("device lost")
+
+    ev2 = BatchedEvaluator(bad, 2)
+    errs = []
+
+    def c2():
+        try:
+            ev2.evaluate(np.zeros(3))
+        except RuntimeError as e:
+            errs.append(e)
+        finally:
+            ev2.leave()
+
+    ts = [threading.Thread(target=c2) for _ in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=30)
+    assert len(errs) == 2

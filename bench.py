@@ -412,6 +412,26 @@ def main():
             h.close()
         del others, lanes
         torch.cuda.empty_cache()
+        # the same K chains through ONE handle and ONE batched call per round (mi_gp_lml_batch: blockIdx.z = chain; how
+        # GPMCMC.fit schedules the chains of a GPU since round 4).  Extra record as well.
+        try:
+            TK = np.array([thetas[j % len(thetas)] for j in range(K)])
+            gp.lml_batch(TK)
+            torch.cuda.synchronize(dev)
+            dist.barrier()
+            tb = time.perf_counter()
+            for i in range(csteps):
+                vb = gp.lml_batch(np.array([thetas[(j + i) % len(thetas)] for j in range(K)]))
+                assert np.all(np.isfinite(vb))
+            torch.cuda.synchronize(dev)
+            dist.barrier()
+            tb = torch.tensor([time.perf_counter() - tb], dtype=torch.float64, device=dev)
+            dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+            tb = float(tb.item())
+            conc_rec["batched"] = {"k": K, "evals_per_s": world * K * csteps / tb, "ms_per_batch": tb / csteps * 1e3,
+                                   "entry": "mi_gp_lml_batch (one handle, blockIdx.z = chain)"}
+        except Exception as e:  # noqa: BLE001 - the extra record must not take the headline down
+            conc_rec["batched"] = {"error": str(e)}
 
     # Roofline pass (rank 0): the same evaluations again with HIP events on the handle's own stream
     # around every phase and every GEMM launch.  Look-ahead is switched off for this pass so that

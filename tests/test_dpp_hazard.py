@@ -90,6 +90,77 @@ def test_checker_flags_a_broken_sequence_and_accepts_a_padded_one():
     assert dpp_hazards(padded) == []  # the non-DPP operand (src1) may come straight from the previous instruction
 
 
+
+# ---------------------------------------------------------------- control-flow aware form (round 4)
+def dpp_hazards_cfg(text, need=2):
+    """The same rule along EVERY path into a DPP instruction: the linear walk above only sees the instructions that precede
+    it in the listing, but a DPP instruction that is (or closely follows) a branch target is also preceded at run time by
+    the last instructions of every block that branches to it.  Walks backwards from each DPP instruction through the
+    control-flow graph (fall-through and branch predecessors) until `need` wait states have been seen on that path."""
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_uninit_check as chk
+
+    bad = []
+    for name, insts in chk.parse_disassembly(text).items():
+        addr2idx = {i.addr: k for k, i in enumerate(insts)}
+        preds = {}  # instruction index -> indices of instructions that can execute right before it
+        for k, i in enumerate(insts):
+            falls = not (i.mn in ("s_branch", "s_endpgm", "s_setpc_b64"))
+            if falls and k + 1 < len(insts):
+                preds.setdefault(k + 1, []).append(k)
+            if (i.mn == "s_branch" or i.mn.startswith("s_cbranch")) and i.target in addr2idx:
+                preds.setdefault(addr2idx[i.target], []).append(k)
+        for k, i in enumerate(insts):
+            if not i.mn.endswith("_dpp") or len(i.ops) < 2:
+                continue
+            src0 = _regs(i.ops[1])
+            stack, seen = [(p, 0) for p in preds.get(k, [])], set()
+            while stack:
+                j, waited = stack.pop()
+                if (j, waited) in seen or waited >= need:
+                    continue
+                seen.add((j, waited))
+                pj = insts[j]
+                if pj.mn == "s_nop":
+                    w = waited + (int(pj.mods.strip() or "0", 0) + 1)
+                else:
+                    if pj.mn.startswith("v_") and pj.ops and (_regs(pj.ops[0]) & src0):
+                        bad.append((name, hex(i.addr), i.text, hex(pj.addr), pj.text, waited))
+                        continue
+                    w = waited + 1
+                for q in preds.get(j, []):
+                    stack.append((q, w))
+    return bad
+
+
+def test_cfg_checker_sees_a_hazard_through_a_branch_target():
+    # the producer sits at the end of a block that BRANCHES to the DPP instruction; in the listing an unrelated, padded
+    # block precedes the consumer, so the linear checker is blind to it
+    def listing(pad):
+        lines = ["0000000000001000 <k>:",
+                 "\tv_mul_f64 v[22:23], v[36:37], -v[10:11]                    // 000000001000: D2810016 40021524"]
+        addr = 0x1008
+        if pad:
+            lines.append(f"\ts_nop 1                                                    // {addr:012X}: BF800001")
+            addr += 4
+        lines.append(f"\ts_branch 3                                                 // {addr:012X}: BF820003 <k+{addr + 16 - 0x1000:#x}>")
+        addr += 4
+        lines.append(f"\tv_add_f64 v[2:3], v[4:5], v[6:7]                           // {addr:012X}: D2800002 00020D04")
+        addr += 8
+        lines.append(f"\ts_nop 1                                                    // {addr:012X}: BF800001")
+        addr += 4
+        lines.append(f"\tv_fmac_f64_dpp v[24:25], v[22:23], v[34:35] row_newbcast:1 row_mask:0xf bank_mask:0xf // {addr:012X}: 0830444A FF1522FA")
+        addr += 8
+        lines.append(f"\ts_endpgm                                                   // {addr:012X}: BF810000")
+        return "\n".join(lines) + "\n"
+
+    assert dpp_hazards(listing(False)) == []          # linear walk: v_add, s_nop 1 in front -> looks padded
+    found = dpp_hazards_cfg(listing(False))           # along the branch: v_mul -> s_branch (one wait state) -> DPP read
+    assert len(found) == 1 and found[0][4].startswith("v_mul_f64 v[22:23]"), found
+    assert dpp_hazards_cfg(listing(True)) == []       # s_nop 1 + the branch itself: three wait states on that path
+
 def _device_listing(obj, tmp_path):
     local = str(tmp_path / os.path.basename(obj))
     shutil.copy(obj, local)
@@ -115,3 +186,5 @@ def test_no_dpp_instruction_of_the_library_reads_a_freshly_written_vgpr(tmp_path
         bad = dpp_hazards(text)
         assert not bad, (f"{name}: {len(bad)} DPP reads within 2 wait states of the VALU write of their operand, "
                          f"first: {bad[:3]}")
+        bad = dpp_hazards_cfg(text)  # ... and along every control-flow path into a DPP instruction
+        assert not bad, f"{name}: {len(bad)} DPP reads within 2 wait states of a VALU write on some path, first: {bad[:3]}"

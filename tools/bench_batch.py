@@ -13,6 +13,8 @@ if "--ks" in sys.argv:
 N, d, kern = (int(args[0]), int(args[1]), args[2]) if len(args) >= 3 else (4096, 8, "RBF")
 X, y = synth_problem(N, d, seed=0)
 gp = MiGP(X, y, kern, need_grad=grad)
+for kv in filter(None, os.environ.get("MIGP_OPTS", "").split(",")):  # e.g. MIGP_OPTS=7=512
+    gp.set_option(int(kv.split("=")[0]), int(kv.split("=")[1]))
 th = np.array(theta_sequence(d, 64, seed=0))
 single = (lambda t: gp.lml_grad(t)[0]) if grad else gp.lml
 single(th[0])

@@ -27,7 +27,7 @@ for n in 4096 8192; do
   stats p_${tag}_n$n ${tag}_kernel_stats_lml_n$n.csv
 done
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -- python3 $ROOT/bench.py --steps 2 --warmup 1 --roofline-steps 1 --no-cpu-baseline --no-sharded --chains-per-gpu 0 --grad-steps 0 > $OUT/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -- python3 $ROOT/bench.py --steps 2 --warmup 1 --roofline-steps 1 --no-lookahead --no-cpu-baseline --no-sharded --chains-per-gpu 0 --grad-steps 0 > $OUT/pmc_$c.log 2>&1
 done
 python3 $ROOT/tools/pmc_traffic.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/gemm_traffic.json
 for f in $OUT/p_${tag}_grad.log $OUT/p_${tag}_pred.log; do tail -n 2 $f | cut -c1-200; done

@@ -377,14 +377,19 @@ static hipError_t hand_off(mi_gp_handle* h, hipStream_t from, hipStream_t to) {
 constexpr int LOOKAHEAD_MIN_TILES = 36;
 
 static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int ntc) {
-  const bool la = h->lookahead == 2 || (h->lookahead == 1 && ntc >= LOOKAHEAD_MIN_TILES);
+  // A batched evaluation (blockIdx.z = problem) carries nb times the work per launch, so the look-ahead pays from smaller
+  // problems on (nb = 8: N = 2560 +5 %, 3072 +10 %, 4096 +7 %; nb = 2 from 3072 on).  The super-panel widths stay those of
+  // the single evaluation of the same size, so that a batch returns the single entry points' bits.
+  const int nb = h->btp ? h->btp->nb : 1;
+  const bool la_single = h->lookahead == 2 || (h->lookahead == 1 && ntc >= LOOKAHEAD_MIN_TILES);
+  const bool la = la_single || (h->lookahead == 1 && nb >= 2 && ntc >= (nb >= 8 ? 20 : 24));
   hipStream_t T = h->stream, P = la ? h->pstream : h->stream;
   hipError_t e;
 #define CKE(x) do { e = (x); if (e != hipSuccess) return e; } while (0)
   h->ev_next = 0;
   h->wait_col = -1;
   if (P != T) CKE(hand_off(h, T, P));  // panel stream starts after everything already queued on the main stream (assembly)
-  const int wcap = (P != T && ntc <= NARROW_PANELS_MAX_TILES) ? 4 : 0;
+  const int wcap = (la_single && ntc <= NARROW_PANELS_MAX_TILES) ? 4 : 0;
   int w = pick_w(h, ntc, wcap);
   CKE(chol_panel(h, A, lda, ntr, 0, w, P));
   for (int J = 0; J < ntc;) {
@@ -394,7 +399,7 @@ static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int nt
     // The END of a large factorisation is a small one: below LOOKAHEAD_MIN_TILES trailing columns the cross-stream hand-offs
     // cost more than the overlap returns (that is why small problems run on one stream), so the rest runs on the main
     // stream alone (round 4, option 21; the super-panel widths stay what they were, so the arithmetic does not change).
-    if (P != T && h->lookahead != 2 && ntc - n1 <= h->single_below) P = T;
+    if (P != T && h->lookahead != 2 && ntc - n1 <= h->single_below / nb) P = T;  // (a batch's launches carry nb times the work)
     const int wn = pick_w(h, ntc - n1, wcap);
     const bool bulk = n1 + wn < ntc;
     // tiles of the trailing update of columns [n1 + wn, ntc) / of the whole trailing trapezoid [n1, ntc)

@@ -374,7 +374,8 @@ static hipError_t hand_off(mi_gp_handle* h, hipStream_t from, hipStream_t to) {
 // Below this many tile columns one stream is faster than two: the cross-stream hand-offs cost more than the overlap
 // returns (one stream vs two, end of round 2: N = 2048 0.94 vs 1.01 ms, N = 4096 2.235 vs 2.252, N = 4608 2.513 vs 2.472,
 // N = 5120 2.849 vs 2.820, N = 6144 3.81 vs 3.59, N = 8192 6.35 vs 5.67).
-constexpr int LOOKAHEAD_MIN_TILES = 36;
+constexpr int LOOKAHEAD_MIN_TILES = 28;  // round 4: with the single-stream tail (option 21) two streams win from 28 tile columns on
+                                       // (N = 3584 1.735 -> 1.670 ms, 4096 2.099 -> 2.054; N = 3072 1.372 vs 1.397: one stream stays)
 
 static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int ntc) {
   // A batched evaluation (blockIdx.z = problem) carries nb times the work per launch, so the look-ahead pays from smaller
@@ -399,7 +400,7 @@ static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int nt
     // The END of a large factorisation is a small one: below LOOKAHEAD_MIN_TILES trailing columns the cross-stream hand-offs
     // cost more than the overlap returns (that is why small problems run on one stream), so the rest runs on the main
     // stream alone (round 4, option 21; the super-panel widths stay what they were, so the arithmetic does not change).
-    if (P != T && h->lookahead != 2 && ntc - n1 <= h->single_below / nb) P = T;  // (a batch's launches carry nb times the work)
+    if (P != T && ntc - n1 <= h->single_below / nb) P = T;  // (a batch's launches carry nb times the work)
     const int wn = pick_w(h, ntc - n1, wcap);
     const bool bulk = n1 + wn < ntc;
     // tiles of the trailing update of columns [n1 + wn, ntc) / of the whole trailing trapezoid [n1, ntc)

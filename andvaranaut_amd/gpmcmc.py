@@ -466,7 +466,7 @@ class GPMCMC(ConsumersMixin):
         (one chain per GPU when several are visible: SURVEY.md section 8e).  Chains that share a GPU run on up to
         ``chains_per_device`` handles at once (default: up to 3 while their buffers fit): below N ~ 10^4 one evaluation
         is bound by the serial panel chain and leaves most of the chip idle -- three concurrent handles on one MI355X
-        deliver 2.7x the evaluations/s at N=1024, 2.2x at N=4096, 1.25x at N=8192 (tools/dev_concurrent.py), and every
+        deliver 2.7x the evaluations/s at N=1024, 2.2x at N=4096, 1.25x at N=8192 (tools/archive/dev_concurrent.py), and every
         chain's draws are the same as when it runs alone (evaluations are deterministic per handle).
         Round 4: without warp parameters (and unless ``chains_per_device`` / ``batched=False`` ask for lanes) the chains of a
         device share ONE handle and meet in one batched evaluation per leapfrog step (blockIdx.z = chain): N=4096 LML

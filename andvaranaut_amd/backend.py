@@ -364,8 +364,13 @@ class MiGP:
 
     def close(self):
         if getattr(self, "h", None) is not None:
-            self.lib.mi_gp_destroy(self.h)
+            self.lib.mi_gp_destroy(self.h)  # synchronises the handle's streams first
             self.h = None
+        # the device buffers the handle borrowed (a batch holds K-fold copies of K, U, K^-1)
+        for name in ("_bK", "_bZ", "_bW", "K_t", "Z_t", "W_t", "_work", "_work2", "_gx_t"):
+            if hasattr(self, name):
+                setattr(self, name, None)
+        self._batch_k = 0
 
     def __del__(self):
         try:

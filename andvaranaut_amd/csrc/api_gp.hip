@@ -33,6 +33,9 @@ struct mi_gp_handle {
   int band_rows;    // band height of the band-column-major tile order of uniform-k trapezoid launches
   int split_tiles;  // option 18: tiles of a bulk update that run one workgroup per CU beside the chain; the rest two per CU (0: no split)
   int split_min_rest;  // option 19: ... only when at least this many tiles remain for the second part
+  int asm_split;       // option 24: assemble the first super-panel's columns first, the rest beside its factorisation (default 1)
+  hipEvent_t asm_ev;   // recorded behind the first part; the panel stream starts there
+  bool asm_ev_valid;
   int single_below;    // option 21: trailing tile columns at or below which a two-stream factorisation continues on one stream (0: never)
   int merge_min_tiles; // option 20: trailing sizes (tile columns) from which the next super-panel's update rides at the head of the
                        // trailing update's enumeration instead of in launches of its own (0: never)
@@ -46,6 +49,8 @@ struct mi_gp_handle {
   double* gxs_dev;      // [grad_x_splits][n][d] partial dLML/dX (allocated on first mi_gp_grad_x)
   double* grad_host;    // pinned [ntheta]
   int* info_dev;
+  double* lr_part_dev;  // [2 * LML_REDUCE_BLOCKS] slice sums of lml_reduce_kernel
+  unsigned* lr_sync_dev;  // its ticket (zero between evaluations)
   double* out_host;     // pinned [16]
   double* theta_host;   // pinned
   // profiling
@@ -67,6 +72,8 @@ struct mi_gp_handle {
   int batch_cap;           // problems the batch scratch below is sized for
   double *b_theta_dev, *b_dinv_dev, *b_alpha_dev, *b_part_dev, *b_grad_host, *b_out_host, *b_theta_host;
   int* b_info_dev;
+  double* b_lr_part_dev;
+  unsigned* b_lr_sync_dev;
   bool factored;
   bool have_u;             // Z_dev holds U = L^-T and alpha_dev = K^-1 y of the last mi_gp_factor (mi_gp_predict_grad)
   bool have_kinv;          // W_dev holds K^-1 (lower) and alpha_dev = K^-1 y of the last mi_gp_lml_grad
@@ -93,6 +100,7 @@ static void release_handle(mi_gp_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   (void)hipFree(h->theta_dev); (void)hipFree(h->dinv_dev); (void)hipFree(h->info_dev);
   (void)hipFree(h->alpha_dev); (void)hipFree(h->part_dev); (void)hipFree(h->gxs_dev);
+  (void)hipFree(h->lr_part_dev); (void)hipFree(h->lr_sync_dev); (void)hipFree(h->b_lr_part_dev); (void)hipFree(h->b_lr_sync_dev);
   (void)hipFree(h->b_theta_dev); (void)hipFree(h->b_dinv_dev); (void)hipFree(h->b_alpha_dev); (void)hipFree(h->b_part_dev);
   (void)hipFree(h->b_info_dev);
   if (h->b_grad_host) (void)hipHostFree(h->b_grad_host);
@@ -104,6 +112,7 @@ static void release_handle(mi_gp_handle* h) {
   for (int i = 0; i < 8; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
   for (auto& ev : h->gemm_ev) (void)hipEventDestroy(ev);
   for (auto& ev : h->ev_pool) (void)hipEventDestroy(ev);
+  if (h->asm_ev) (void)hipEventDestroy(h->asm_ev);
   if (h->pstream) (void)hipStreamDestroy(h->pstream);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -158,6 +167,8 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   h->split_min_rest = 1024;
   h->merge_min_tiles = 72;
   h->single_below = 16;
+  h->asm_split = 1;
+  h->asm_ev_valid = false;
   // round-2 A/B (tools/dev_ab_opts.py, interleaved in one process): bulk updates at one workgroup per CU whenever the
   // panel chain runs beside them (N = 16384: 29.99 -> 28.97 ms) and 8-tile super-panels at every size (N = 2048 1.045 ->
   // 1.017 ms, 4096 2.470 -> 2.388, 8192 6.417 -> 6.348, 16384 28.59 -> 28.39 against the 8 / 4 split of round 1)
@@ -169,9 +180,14 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   if (e == hipSuccess) e = hipMalloc(&h->part_dev, sizeof(double) * (size_t)grad_contract_blocks(h->n) * h->ntheta);
   if (e == hipSuccess) e = hipHostMalloc(&h->grad_host, sizeof(double) * h->ntheta);
   if (e == hipSuccess) e = hipMalloc(&h->info_dev, sizeof(int) * 4);
+  if (e == hipSuccess) e = hipMalloc(&h->lr_part_dev, sizeof(double) * 2 * LML_REDUCE_BLOCKS);
+  if (e == hipSuccess) e = hipMalloc(&h->lr_sync_dev, sizeof(unsigned));
+  if (e == hipSuccess) e = hipMemset(h->lr_sync_dev, 0, sizeof(unsigned));
   if (e == hipSuccess) e = hipHostMalloc(&h->out_host, sizeof(double) * 16);
   if (e == hipSuccess) e = hipHostMalloc(&h->theta_host, sizeof(double) * h->ntheta);
   for (int i = 0; i < 8 && e == hipSuccess; ++i) e = hipEventCreate(&h->ev[i]);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->asm_ev, hipEventDisableTiming);
+  if (e == hipSuccess) e = assemble_enable_lds();
   if (e == hipSuccess) e = gemm_f64_enable_lds();
   if (e == hipSuccess) e = leaf_enable_lds();
   if (e != hipSuccess) {
@@ -220,6 +236,7 @@ extern "C" int mi_gp_set_option(mi_gp_handle* h, int what, int value) {
   else if (what == 19) h->split_min_rest = value;
   else if (what == 20) h->merge_min_tiles = value;
   else if (what == 21) h->single_below = value;
+  else if (what == 24) h->asm_split = value ? 1 : 0;
   else if (what == 9) h->tail_small = value ? 1 : 0;
   else {
     snprintf(h->err, sizeof(h->err), "mi_gp_set_option: unknown option %d", what);
@@ -389,7 +406,13 @@ static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int nt
 #define CKE(x) do { e = (x); if (e != hipSuccess) return e; } while (0)
   h->ev_next = 0;
   h->wait_col = -1;
-  if (P != T) CKE(hand_off(h, T, P));  // panel stream starts after everything already queued on the main stream (assembly)
+  // the panel stream starts after what is queued on the main stream (assembly) -- or, when the assembly was split, after its
+  // first part (the first super-panel's columns); the first main-stream update sits behind the second part anyway
+  if (P != T) {
+    if (h->asm_ev_valid && P == h->pstream) CKE(hipStreamWaitEvent(P, h->asm_ev, 0));
+    else CKE(hand_off(h, T, P));
+  }
+  h->asm_ev_valid = false;
   const int wcap = (la_single && ntc <= NARROW_PANELS_MAX_TILES) ? 4 : 0;
   int w = pick_w(h, ntc, wcap);
   CKE(chol_panel(h, A, lda, ntr, 0, w, P));
@@ -486,14 +509,30 @@ static int enqueue_factor(mi_gp_handle* h, int noise_form, bool prof) {
   // first kernel of the evaluation: y rows, the bad-pivot word, and theta from the pinned host buffer to theta_dev
   HCK(launch_set_yrows(h->buf.K_dev, h->buf.lda, h->np, h->np, h->buf.y_dev, h->n, h->stream, h->info_dev, h->theta_host,
                        h->theta_dev, h->ntheta, h->btp), "set_yrows");
-  HCK(launch_assemble(h->spec, h->theta_dev, h->buf.X_dev, h->n, h->buf.X_dev, h->n, h->buf.K_dev, h->buf.lda, h->np,
-                      h->np, 1, noise_form, h->stream, 0, h->diag_dev, h->btp), "assemble");
+  // Two-stream evaluations of one problem: the first super-panel's factorisation needs only the first 1024 columns of K and
+  // runs on an otherwise idle chip (0.73 ms at N = 16384).  Those columns (the first two 512-column runs of every tile row)
+  // are assembled first; the rest follows on the main stream one workgroup per CU, beside that factorisation (option 24).
+  h->asm_ev_valid = false;
+  const bool two_stream = h->lookahead == 2 || (h->lookahead == 1 && h->ntc >= LOOKAHEAD_MIN_TILES);
+  const int w0 = h->cfg.panel_tiles > 0 ? h->cfg.panel_tiles : 8;  // at least the first super-panel's columns
+  const int c0 = (w0 * 128 + 511) / 512;
+  if (h->asm_split && two_stream && !h->btp && h->ntc >= 96 && 4 * c0 < h->ntc) {  // (N = 8192: 5.62 -> 5.65 ms, N = 16384: 26.66 -> 26.57)
+    HCK(launch_assemble(h->spec, h->theta_dev, h->buf.X_dev, h->n, h->buf.X_dev, h->n, h->buf.K_dev, h->buf.lda, h->np,
+                        h->np, 1, noise_form, h->stream, 0, h->diag_dev, h->btp, 0, c0, 0), "assemble (first super-panel)");
+    HCK(hipEventRecord(h->asm_ev, h->stream), "assemble event");
+    h->asm_ev_valid = true;
+    HCK(launch_assemble(h->spec, h->theta_dev, h->buf.X_dev, h->n, h->buf.X_dev, h->n, h->buf.K_dev, h->buf.lda, h->np,
+                        h->np, 1, noise_form, h->stream, 0, h->diag_dev, h->btp, c0, 2147483647, 1), "assemble (rest)");
+  } else {
+    HCK(launch_assemble(h->spec, h->theta_dev, h->buf.X_dev, h->n, h->buf.X_dev, h->n, h->buf.K_dev, h->buf.lda, h->np,
+                        h->np, 1, noise_form, h->stream, 0, h->diag_dev, h->btp), "assemble");
+  }
   if (prof) (void)hipEventRecord(h->ev[1], h->stream);
   HCK(cholesky(h, h->buf.K_dev, h->buf.lda, h->ntc + 1, h->ntc), "cholesky");
   if (prof) (void)hipEventRecord(h->ev[2], h->stream);
   // the scalars go straight to the pinned host buffer (device-visible): no download launch behind the reduction
   HCK(launch_lml_reduce(h->buf.K_dev, h->buf.lda, h->buf.K_dev + (long)h->np * h->buf.lda, h->n, h->out_host, h->stream, h->info_dev,
-                        h->btp), "lml_reduce");
+                        h->btp, h->lr_part_dev, h->lr_sync_dev), "lml_reduce");
   if (prof) (void)hipEventRecord(h->ev[3], h->stream);
   return 0;
 }
@@ -740,7 +779,8 @@ extern "C" int mi_gp_set_batch(mi_gp_handle* h, const mi_gp_batch_buffers* b) {
   if (b->count > h->batch_cap) {
     (void)hipStreamSynchronize(h->stream);
     (void)hipFree(h->b_theta_dev); (void)hipFree(h->b_dinv_dev); (void)hipFree(h->b_alpha_dev); (void)hipFree(h->b_part_dev);
-    (void)hipFree(h->b_info_dev);
+    (void)hipFree(h->b_info_dev); (void)hipFree(h->b_lr_part_dev); (void)hipFree(h->b_lr_sync_dev);
+    h->b_lr_part_dev = nullptr; h->b_lr_sync_dev = nullptr;
     if (h->b_grad_host) (void)hipHostFree(h->b_grad_host);
     if (h->b_out_host) (void)hipHostFree(h->b_out_host);
     if (h->b_theta_host) (void)hipHostFree(h->b_theta_host);
@@ -753,6 +793,9 @@ extern "C" int mi_gp_set_batch(mi_gp_handle* h, const mi_gp_batch_buffers* b) {
     HCK(hipMalloc(&h->b_alpha_dev, sizeof(double) * k * h->np), "batch scratch");
     HCK(hipMalloc(&h->b_part_dev, sizeof(double) * k * (size_t)grad_contract_blocks(h->n) * h->ntheta), "batch scratch");
     HCK(hipMalloc(&h->b_info_dev, sizeof(int) * 4 * k), "batch scratch");
+    HCK(hipMalloc(&h->b_lr_part_dev, sizeof(double) * 2 * LML_REDUCE_BLOCKS * k), "batch scratch");
+    HCK(hipMalloc(&h->b_lr_sync_dev, sizeof(unsigned) * k), "batch scratch");
+    HCK(hipMemset(h->b_lr_sync_dev, 0, sizeof(unsigned) * k), "batch scratch");
     HCK(hipHostMalloc(&h->b_grad_host, sizeof(double) * k * h->ntheta), "batch scratch");
     HCK(hipHostMalloc(&h->b_out_host, sizeof(double) * 16 * k), "batch scratch");
     HCK(hipHostMalloc(&h->b_theta_host, sizeof(double) * k * h->ntheta), "batch scratch");
@@ -778,6 +821,9 @@ static int batch_internal(mi_gp_handle* h, int k, const double* thetas, int what
   double *theta_dev0 = h->theta_dev, *dinv0 = h->dinv_dev, *alpha0 = h->alpha_dev, *part0 = h->part_dev, *grad0 = h->grad_host,
          *out0 = h->out_host, *thost0 = h->theta_host;
   int* info0 = h->info_dev;
+  double* lrp0 = h->lr_part_dev;
+  unsigned* lrs0 = h->lr_sync_dev;
+  h->lr_part_dev = h->b_lr_part_dev; h->lr_sync_dev = h->b_lr_sync_dev;
   h->buf.K_dev = h->bbuf.K_dev; h->buf.Z_dev = h->bbuf.Z_dev; h->buf.W_dev = h->bbuf.W_dev;
   h->theta_dev = h->b_theta_dev; h->dinv_dev = h->b_dinv_dev; h->alpha_dev = h->b_alpha_dev; h->part_dev = h->b_part_dev;
   h->grad_host = h->b_grad_host; h->out_host = h->b_out_host; h->theta_host = h->b_theta_host; h->info_dev = h->b_info_dev;
@@ -800,6 +846,7 @@ static int batch_internal(mi_gp_handle* h, int k, const double* thetas, int what
   h->buf = buf0;
   h->theta_dev = theta_dev0; h->dinv_dev = dinv0; h->alpha_dev = alpha0; h->part_dev = part0; h->grad_host = grad0;
   h->out_host = out0; h->theta_host = thost0; h->info_dev = info0;
+  h->lr_part_dev = lrp0; h->lr_sync_dev = lrs0;
   if (r != 0) return r;
   for (int p = 0; p < k; ++p) {
     const int info = (int)h->b_out_host[16 * p + 3];

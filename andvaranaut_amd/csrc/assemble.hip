@@ -51,11 +51,14 @@ constexpr int TPW = 8;                  // tiles per workgroup
 constexpr int SROWS = AT / (256 / DCH);  // rows a thread stages per 64-row block: 8
 
 // RESIDENT: the host guarantees nkern == 1 and d <= DCH (only the prefetching form is compiled), else only the general form.
+// dynamic LDS that makes the kernel's request exceed half a CU (its static image is ~37 KB)
+constexpr size_t ASM_ONE_PER_CU_PAD = 46 * 1024;
+
 template <int KID_STATIC, bool RESIDENT>
 __global__ __launch_bounds__(256, (KID_STATIC >= 0 && KID_STATIC != KID_RATQUAD) ? 3 : 2) void assemble_kernel(
     KernSpec spec, const double* __restrict__ theta_in, const double* __restrict__ X1, int n1, const double* __restrict__ X2, int n2,
     double* __restrict__ K_in, long ldk, int rows_pad, int cols_pad, int sym, int noise_form, int diag_shift,
-    const double* __restrict__ extra_diag, long sK, int stheta) {
+    const double* __restrict__ extra_diag, long sK, int stheta, int chunk_lo, int chunk_hi) {
   const double* __restrict__ theta = theta_in + (long)blockIdx.z * stheta;  // batched evaluation: problem blockIdx.z
   double* __restrict__ K = K_in + (long)blockIdx.z * sK;
   __shared__ __attribute__((aligned(16))) double Xi[AT * DLD];
@@ -80,6 +83,7 @@ __global__ __launch_bounds__(256, (KID_STATIC >= 0 && KID_STATIC != KID_RATQUAD)
     chunk = blockIdx.x % nrun;
     tj_end = cols_pad / AT;
   }
+  if (chunk < chunk_lo || chunk >= chunk_hi) return;  // column-range launch (runs of TPW tiles = 512 columns; uniform per workgroup)
   const int tj0 = chunk * TPW;
   const int tj1 = min(tj0 + TPW, tj_end);
   const int i0 = ti * AT;
@@ -262,28 +266,36 @@ __global__ void set_yrows_kernel(double* __restrict__ K, long ldk, int row0, int
 }
 
 // out[0] = LML, out[1] = sum log L_ii, out[2] = |beta|^2   (gpmcmc.py:316-318 / MvNormal.logp)
-// One 256-thread workgroup: 16 independent diagonal gathers in flight per thread (the strided diagonal walk is pure
-// latency), partial sums combined in a fixed order (bit-reproducible).
+// LR_BLOCKS workgroups per problem, each sums a contiguous slice of the diagonal (the strided diagonal walk and fp64 log are
+// pure latency: one workgroup took 52 us at N = 16384); the last one to finish (a ticket in `sync`) adds the slices' partial
+// sums in slice order -- the summation order is fixed, the result bit-reproducible.
+constexpr int LR_BLOCKS = LML_REDUCE_BLOCKS;
 __global__ __launch_bounds__(256) void lml_reduce_kernel(const double* __restrict__ L, long ld,
                                                          const double* __restrict__ beta, int n,
                                                          double* __restrict__ out, const int* __restrict__ info, long sK,
-                                                         int sout, int sinfo) {
+                                                         int sout, int sinfo, double* __restrict__ part,
+                                                         unsigned* __restrict__ sync) {
   L += (long)blockIdx.z * sK;  // batched evaluation: problem blockIdx.z
   beta += (long)blockIdx.z * sK;
   out += (long)blockIdx.z * sout;
   if (info) info += (long)blockIdx.z * sinfo;
+  if (part) part += (long)blockIdx.z * 2 * LR_BLOCKS;
+  if (sync) sync += blockIdx.z;
   __shared__ double s1[256], s2[256];
+  __shared__ unsigned ticket;
+  const int per = gridDim.x == 1 ? n : ((n + LR_BLOCKS - 1) / LR_BLOCKS + 255) / 256 * 256;
+  const int lo = blockIdx.x * per, hi = min(n, lo + per);
   double a = 0.0, b = 0.0;
-  for (int i0 = threadIdx.x; i0 < n; i0 += 256 * 16) {
-    double dv[16], bv[16];
+  for (int i0 = lo + threadIdx.x; i0 < hi; i0 += 256 * 4) {
+    double dv[4], bv[4];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
+    for (int u = 0; u < 4; ++u) {
       const int i = i0 + 256 * u;
-      dv[u] = (i < n) ? L[(long)i * ld + i] : 1.0;
-      bv[u] = (i < n) ? beta[i] : 0.0;
+      dv[u] = (i < hi) ? L[(long)i * ld + i] : 1.0;
+      bv[u] = (i < hi) ? beta[i] : 0.0;
     }
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
+    for (int u = 0; u < 4; ++u) {
       a += log(dv[u]);
       b += bv[u] * bv[u];
     }
@@ -298,17 +310,42 @@ __global__ __launch_bounds__(256) void lml_reduce_kernel(const double* __restric
     }
     __syncthreads();
   }
+  if (gridDim.x == 1) {  // no scratch given (block-level entry mi_gp_lml_partial): one workgroup does it all
+    if (threadIdx.x == 0) {
+      out[1] = s1[0];
+      out[2] = s2[0];
+      out[0] = -0.5 * (double)n * 1.8378770664093453 - 0.5 * s2[0] - s1[0];
+      if (info) out[3] = (double)info[0];
+    }
+    return;
+  }
   if (threadIdx.x == 0) {
-    out[1] = s1[0];
-    out[2] = s2[0];
-    out[0] = -0.5 * (double)n * 1.8378770664093453 - 0.5 * s2[0] - s1[0];
+    part[2 * blockIdx.x] = s1[0];
+    part[2 * blockIdx.x + 1] = s2[0];
+    __threadfence();
+    ticket = atomicAdd(sync, 1u);
+  }
+  __syncthreads();
+  if (ticket != LR_BLOCKS - 1) return;
+  if (threadIdx.x == 0) {
+    __threadfence();
+    double t1 = 0.0, t2 = 0.0;
+    for (int k = 0; k < LR_BLOCKS; ++k) {
+      t1 += __hip_atomic_load(part + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      t2 += __hip_atomic_load(part + 2 * k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    out[1] = t1;
+    out[2] = t2;
+    out[0] = -0.5 * (double)n * 1.8378770664093453 - 0.5 * t2 - t1;
     if (info) out[3] = (double)info[0];  // the bad-pivot word rides in the same download as the scalars
+    *sync = 0u;                          // ready for the next evaluation
   }
 }
 
 hipError_t launch_assemble(const KernSpec& spec, const double* theta, const double* X1, int n1, const double* X2,
                            int n2, double* K, long ldk, int rows_pad, int cols_pad, int sym, int noise_form,
-                           hipStream_t stream, int diag_shift, const double* extra_diag, const Batch* bt) {
+                           hipStream_t stream, int diag_shift, const double* extra_diag, const Batch* bt, int chunk_lo,
+                           int chunk_hi, int one_per_cu) {
   int nblk;  // runs of up to TPW tiles of one tile row
   if (sym) {
     const int nt = rows_pad / AT, G = nt / TPW, rem = nt % TPW;
@@ -322,12 +359,15 @@ hipError_t launch_assemble(const KernSpec& spec, const double* theta, const doub
   const dim3 grid(nblk, 1, bt ? bt->nb : 1);
   const long sK = bt ? bt->sK : 0;
   const int sth = bt ? bt->stheta : 0;
+  // one_per_cu: unused dynamic LDS pushes the request over half a CU, so that the panel chain's leaf (which needs a CU to
+  // itself) finds one as soon as a workgroup of this launch retires
+  const size_t pad = one_per_cu ? ASM_ONE_PER_CU_PAD : 0;
 #define MIGP_ASM(KID)                                                                                                              \
   do {                                                                                                                             \
     if (resident)                                                                                                                  \
-      assemble_kernel<KID, true><<<grid, 256, 0, stream>>>(spec, theta, X1, n1, X2, n2, K, ldk, rows_pad, cols_pad, sym, noise_form, ds, ed, sK, sth);  \
+      assemble_kernel<KID, true><<<grid, 256, pad, stream>>>(spec, theta, X1, n1, X2, n2, K, ldk, rows_pad, cols_pad, sym, noise_form, ds, ed, sK, sth, chunk_lo, chunk_hi);  \
     else                                                                                                                           \
-      assemble_kernel<KID, false><<<grid, 256, 0, stream>>>(spec, theta, X1, n1, X2, n2, K, ldk, rows_pad, cols_pad, sym, noise_form, ds, ed, sK, sth); \
+      assemble_kernel<KID, false><<<grid, 256, pad, stream>>>(spec, theta, X1, n1, X2, n2, K, ldk, rows_pad, cols_pad, sym, noise_form, ds, ed, sK, sth, chunk_lo, chunk_hi); \
   } while (0)
   if (spec.nkern != 1) MIGP_ASM(-1);
   else if (spec.kid[0] == KID_RBF) MIGP_ASM(KID_RBF);
@@ -337,6 +377,20 @@ hipError_t launch_assemble(const KernSpec& spec, const double* theta, const doub
   else MIGP_ASM(KID_RATQUAD);
 #undef MIGP_ASM
   return hipGetLastError();
+}
+
+hipError_t assemble_enable_lds() {
+  const int ldsb = (int)ASM_ONE_PER_CU_PAD;
+#define MIGP_ATTR(KID)                                                                                                      \
+  do {                                                                                                                      \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_kernel<KID, true>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);  \
+    if (e != hipSuccess) return e;                                                                                          \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_kernel<KID, false>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);            \
+    if (e != hipSuccess) return e;                                                                                          \
+  } while (0)
+  MIGP_ATTR(-1); MIGP_ATTR(KID_RBF); MIGP_ATTR(KID_MATERN52); MIGP_ATTR(KID_MATERN32); MIGP_ATTR(KID_EXPONENTIAL); MIGP_ATTR(KID_RATQUAD);
+#undef MIGP_ATTR
+  return hipSuccess;
 }
 
 hipError_t launch_set_yrows(double* K, long ldk, int row0, int cols_pad, const double* y, int n, hipStream_t stream,
@@ -350,9 +404,9 @@ hipError_t launch_set_yrows(double* K, long ldk, int row0, int cols_pad, const d
 }
 
 hipError_t launch_lml_reduce(const double* L, long ld, const double* beta, int n, double* out, hipStream_t stream,
-                             const int* info, const Batch* bt) {
-  lml_reduce_kernel<<<dim3(1, 1, bt ? bt->nb : 1), 256, 0, stream>>>(L, ld, beta, n, out, info, bt ? bt->sK : 0, bt ? bt->sout : 0,
-                                                                     bt ? bt->sinfo : 0);
+                             const int* info, const Batch* bt, double* part, unsigned* sync) {
+  lml_reduce_kernel<<<dim3((part && sync) ? LR_BLOCKS : 1, 1, bt ? bt->nb : 1), 256, 0, stream>>>(L, ld, beta, n, out, info, bt ? bt->sK : 0,
+                                                                             bt ? bt->sout : 0, bt ? bt->sinfo : 0, part, sync);
   return hipGetLastError();
 }
 

@@ -484,7 +484,7 @@ static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int nt
     if (bulk && P != T) {
       // Early super-panels are bound by the bulk update, not by the chain (the panel stream idles for most of it): only the
       // first split_tiles tiles run one workgroup per CU -- the mode that leaves every CU room for the chain's leaf /
-      // strip / in-panel workgroups but costs the kernel ~10 % -- and the rest runs two per CU once the chain is through
+      // strip / in-panel workgroups (and costs the kernel 5 % even alone) -- and the rest runs two per CU once the chain is through
       // (same tiles, same kernels: bit-identical results).  split_tiles ~ what the update gets done while a chain runs.
       if (low && h->split_tiles > 0 && btiles >= h->split_tiles + h->split_min_rest) {
         CKE(syrk_trapezoid(h, A, lda, ntr, n1 + wn, bc, J, w, T, 1, 0, h->split_tiles));

@@ -69,6 +69,7 @@ struct mi_gp_shard {
   hipEvent_t ev_ready = nullptr, ev_staged = nullptr, ev_side_done = nullptr, ev_bulk = nullptr;
   bool staged_pending = false, ready_valid = false, bulk_valid = false;
   int bulk_one_per_cu = 1;
+  int split_tiles = 2048;  // option 4: tiles of a bulk update that run one workgroup per CU beside this rank's chain (0: all)
   int early_next = 1;  // option 2: update the panel this rank factors next step first and alone (see mi_gp_shard_step)
   int chain_on_main = 0;  // option 3: the owner chain runs on the main stream ahead of the bulk update (default: world > 1)
   int prof = 0;
@@ -172,6 +173,7 @@ extern "C" int mi_gp_shard_set_option(mi_gp_shard* s, int what, int value) {
   else if (what == 1) s->prof = value ? 1 : 0;
   else if (what == 2) s->early_next = value ? 1 : 0;
   else if (what == 3) s->chain_on_main = value ? 1 : 0;
+  else if (what == 4) s->split_tiles = value;
   else { snprintf(s->err, sizeof(s->err), "mi_gp_shard_set_option: unknown option %d", what); return -1; }
   return 0;
 }
@@ -253,6 +255,16 @@ static hipError_t update_bulk(mi_gp_shard* s, int li0, int j, const double* buf,
   p.pl_abase = j * s->pwt;
   p.pl_rows = s->ntr;
   p.pl_tiles = s->table[s->nown].x - s->table[li0].x;
+  // beside this rank's own chain only the first split_tiles tiles run one workgroup per CU, the rest two per CU once the
+  // chain is through (the single-GPU driver's split, api_gp.hip cholesky(); same tiles, same kernels)
+  if (one_per_cu && s->split_tiles > 0 && p.pl_tiles >= s->split_tiles + 1024) {
+    p.tile_cnt = s->split_tiles;
+    hipError_t e = launch_gemm_f64(p, 0, 0, 1, st);
+    if (e != hipSuccess) return e;
+    p.one_per_cu = 0;
+    p.tile0 = s->split_tiles;
+    p.tile_cnt = p.pl_tiles;
+  }
   return launch_gemm_f64(p, 0, 0, 1, st);
 }
 

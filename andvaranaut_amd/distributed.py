@@ -157,7 +157,8 @@ class DistGP:
 
     def set_option(self, what, value):
         """mi_gp_shard_set_option: 0 bulk updates one workgroup per CU beside the chain, 1 per-step events, 2 early update,
-        3 chain on the main stream ahead of the bulk update (default on several ranks)."""
+        3 chain on the main stream ahead of the bulk update (default on several ranks), 4 tiles of a bulk update that run one
+        workgroup per CU beside this rank's chain, the rest two per CU (default 2048, 0: all)."""
         self._scheck(self.lib.mi_gp_shard_set_option(self.sh, int(what), int(value)), "mi_gp_shard_set_option")
 
     def step_times(self):

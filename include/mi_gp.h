@@ -273,6 +273,8 @@ int mi_gp_shard_finish(mi_gp_shard* s, void* main_stream, void* side_stream);
  *            instead of beside it on side_stream (default: 1 when world > 1 -- every other rank waits for that chain, and
  *            alone on the chip it is 2-3x shorter than next to a bulk update; 0 on one rank).  Either way side_stream is
  *            ordered behind the staging when the call returns: the caller broadcasts the panel under side_stream.
+ * what = 4: tiles of a bulk update that run one workgroup per CU beside this rank's own chain, the rest two per CU (2048;
+ *            0: the whole update one per CU).
  * Reproducibility: the sharded factorisation is bit-reproducible for a FIXED world size, panel width and option set.
  * Options 2 and 3 and the world size change which launches update a panel (the early next-panel update goes through the
  * ordinary launcher and may run on 64x64 tiles where the panel-list launch uses 128x128), i.e. they regroup sums: results

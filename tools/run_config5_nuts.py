@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--tune", type=int, default=1000)
     ap.add_argument("--chains", type=int, default=3)
     ap.add_argument("--out", default="gpurun_out/config5_nuts.json")
+    ap.add_argument("--batched", action="store_true", help="ONE handle; the chains meet in one mi_gp_lml_grad_batch call per leapfrog step")
     args = ap.parse_args()
 
     from andvaranaut_amd import MiGP
@@ -71,7 +72,11 @@ def main():
     N, d = args.n, args.d
     X, y = synth_problem(N, d, seed=1)
     model = HyperModel(d, ["RBF"], noise=True, jitter=1e-6)
-    handles = [MiGP(X, y, "RBF") for _ in range(args.chains)]
+    handles = [MiGP(X, y, "RBF") for _ in range(1 if args.batched else args.chains)]
+    ev = None
+    if args.batched:
+        from andvaranaut_amd.batching import BatchedEvaluator
+        ev = BatchedEvaluator(handles[0].lml_grad_batch, args.chains)
     t0 = time.perf_counter()
     qmap, info = find_MAP(lambda q: model.logp_dlogp(q, handles[0].lml_grad, jacobian=False), model.initial_point())
     t_map = time.perf_counter() - t0
@@ -82,11 +87,15 @@ def main():
 
     def lane(c):
         try:
-            f = lambda q: model.logp_dlogp(q, handles[c].lml_grad)  # noqa: E731  (pm.sample: density WITH the Jacobian)
+            fn = ev.evaluate if ev is not None else handles[c].lml_grad
+            f = lambda q: model.logp_dlogp(q, fn)  # noqa: E731  (pm.sample: density WITH the Jacobian)
             res[c] = sample_chain(f, model.initial_point(), draws=args.draws, tune=args.tune, seed=seeds[c],
                                   progressbar=(c == 0))
         except Exception as e:  # noqa: BLE001
             errs.append(repr(e))
+        finally:
+            if ev is not None:
+                ev.leave()
 
     t0 = time.perf_counter()
     ths = [threading.Thread(target=lane, args=(c,)) for c in range(args.chains)]
@@ -108,7 +117,9 @@ def main():
     nleap = int(sum(r["n_leapfrog"] for r in res))
     pts = [model.point_dict(v) for v in pooled[:: max(1, len(pooled) // 500)]]
     out = {
-        "workload": f"RBF GP hyper-parameter posterior, N={N} d={d}, {args.chains} NUTS chains sharing one MI355X (one handle + host thread each)",
+        "workload": f"RBF GP hyper-parameter posterior, N={N} d={d}, {args.chains} NUTS chains sharing one MI355X "
+                    + ("(ONE handle, one batched evaluation per leapfrog round: blockIdx.z = chain)" if args.batched else "(one handle + host thread each)"),
+        "batched_rounds": (ev.rounds if ev is not None else None), "batched_mean_k": (ev.evaluations / max(ev.rounds, 1) if ev is not None else None),
         "reference": "pm.sample defaults (gpmcmc.py:351): 1000 tune + 1000 draws, target_accept 0.8, max_treedepth 10",
         "draws": args.draws, "tune": args.tune, "chains": args.chains,
         "seconds": dt, "leapfrog_steps": nleap, "grad_evals_per_s_all_chains": nleap / dt,

@@ -186,6 +186,6 @@ def sample_chain(logp_dlogp, q0, draws=1000, tune=1000, target_accept=0.8, max_t
             depths.append(depth)
             div += int(diverged)
         if progressbar and (it + 1) % 100 == 0:
-            print(f"  NUTS {it + 1}/{tune + draws} eps={eps:.3g} depth={depth} lp={v:.4f}")
+            print(f"  NUTS {it + 1}/{tune + draws} eps={eps:.3g} depth={depth} lp={v:.4f}", flush=True)
     return {"q": qs, "lp": lps, "step_size": eps, "n_leapfrog": nleap, "diverging": div,
             "mean_tree_depth": float(np.mean(depths)) if depths else 0.0}

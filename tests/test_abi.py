@@ -40,6 +40,10 @@ def test_bad_arguments_are_reported_not_crashed():
     assert lib.mi_gp_trsm_block(None, 16, None, 0, 1, None, 16, 128, None) == -1
     assert lib.mi_gp_trmv_upper(None, 16, None, 4, None, None) == -1
     assert lib.mi_gp_grad_contract_block_scratch(1000, 512, 512, 10) == (16 - 8) * 8 * 10  # 16 tile rows, slab = columns 8..15
+    # batched entry points: null handle / buffers
+    assert lib.mi_gp_set_batch(None, None) == -1
+    assert lib.mi_gp_lml_batch(None, 1, None, None, None) == -1
+    assert lib.mi_gp_lml_grad_batch(None, 1, None, None, None, None) == -1
     ids = (ctypes.c_int * 4)(0, 0, 0, 0)
     assert lib.mi_gp_grad_contract_block(2, 1, ids, ids, None, None, 100, None, 16, 64, 0, 64, None, None, 0, None, None) == -1
 

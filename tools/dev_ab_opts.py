@@ -14,6 +14,7 @@ gp = MiGP(X, y, kern, need_grad=grad)
 th = theta_sequence(d, 8, seed=0)
 DEFAULTS = {0: 1, 2: 0, 4: 1 << 20, 5: 0, 6: 0, 7: 1024, 8: 1 << 20, 9: 1, 14: 8, 16: 1, 18: 2048, 19: 1024, 20: 72, 21: 16, 24: 1}
 res = {s: [] for s in sets}
+vals = {}
 reps = 10 if N <= 8192 else 5
 f = (lambda t: gp.lml_grad(t)[0]) if grad else gp.lml
 for rnd in range(4):
@@ -23,11 +24,11 @@ for rnd in range(4):
         for kv in s.split(","):
             if kv and kv != "default":
                 gp.set_option(int(kv.split("=")[0]), int(kv.split("=")[1]))
-        f(th[0])
+        vals[s] = f(th[0])
         t0 = time.perf_counter()
         for i in range(reps):
             f(th[i % 8])
         res[s].append((time.perf_counter() - t0) / reps * 1e3)
 for s in sets:
     v = sorted(res[s])
-    print(f"N={N} {kern} {'lml+grad' if grad else 'lml'} [{s:>14s}] median {np.median(v):8.3f} ms  min {v[0]:8.3f}  max {v[-1]:8.3f}", flush=True)
+    print(f"N={N} {kern} {'lml+grad' if grad else 'lml'} [{s:>14s}] median {np.median(v):8.3f} ms  min {v[0]:8.3f}  max {v[-1]:8.3f}  value {vals[s]!r}", flush=True)

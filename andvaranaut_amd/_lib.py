@@ -117,6 +117,7 @@ def load():
     lib.mi_gp_lml_partial.argtypes = [vp, cl, vp, ci, vp, vp]
     lib.mi_gp_gemm_f64.argtypes = [ci, ci, ci, ci, ci, cd, vp, cl, vp, cl, cd, vp, cl, ci, ci, ci, cl, cl, cl, vp]
     lib.mi_gp_gemm_f64_tuned.argtypes = [ci, ci, ci, ci, ci, cd, vp, cl, vp, cl, cd, vp, cl, ci, ci, ci, ci, ci, ci, vp]
+    lib.mi_gp_gemm_nt_kseg.argtypes = [ci, ci, ci, cd, vp, cl, vp, cl, ci, cl, cd, vp, cl, ci, ci, vp]
     lib.mi_gp_trsm_block.argtypes = [vp, cl, vp, ci, ci, vp, cl, ci, vp]
     lib.mi_gp_trmv_upper.argtypes = [vp, cl, vp, ci, vp, vp]
     lib.mi_gp_grad_contract_block_scratch.argtypes = [ci, ci, ci, ci]
@@ -127,8 +128,10 @@ def load():
     lib.mi_gp_shard_begin.argtypes = [vp, ci, vp, vp]
     lib.mi_gp_shard_step.argtypes = [vp, ci, vp, vp]
     lib.mi_gp_shard_finish.argtypes = [vp, vp, vp]
+    lib.mi_gp_shard_wait_piece.argtypes = [vp, ci, vp]
     lib.mi_gp_shard_set_option.argtypes = [vp, ci, ci]
     lib.mi_gp_shard_times.argtypes = [vp, dp, ci]
+    lib.mi_gp_shard_piece_times.argtypes = [vp, dp, ci]
     lib.mi_gp_shard_chain_stream.argtypes = [vp]
     lib.mi_gp_shard_last_error.argtypes = [vp]
     lib.mi_gp_shard_last_error.restype = ctypes.c_char_p
@@ -166,6 +169,7 @@ EXPORTS = [
     "mi_gp_timers",
     "mi_gp_gemm_f64",
     "mi_gp_gemm_f64_tuned",
+    "mi_gp_gemm_nt_kseg",
     "mi_gp_assemble_block",
     "mi_gp_chol_panel",
     "mi_gp_lml_partial",
@@ -178,8 +182,10 @@ EXPORTS = [
     "mi_gp_shard_begin",
     "mi_gp_shard_step",
     "mi_gp_shard_finish",
+    "mi_gp_shard_wait_piece",
     "mi_gp_shard_set_option",
     "mi_gp_shard_times",
+    "mi_gp_shard_piece_times",
     "mi_gp_shard_chain_stream",
     "mi_gp_shard_last_error",
 ]

@@ -69,6 +69,28 @@ extern "C" int mi_gp_gemm_f64_tuned(int transa, int transb, int m, int n, int k,
   return 0;
 }
 
+// C = beta*C + alpha*A*B^T with A (m rows) and B (n rows) stored as k-segments (GemmParams::kseg): the operand form of the
+// sharded driver's piece-major panel buffers
+extern "C" int mi_gp_gemm_nt_kseg(int m, int n, int k, double alpha, const double* A, long lda, const double* B, long ldb,
+                                  int kseg, long kseg_stride, double beta, double* C, long ldc, int tri, int small_below,
+                                  void* stream) {
+  if (m % 128 || n % 128 || m <= 0 || n <= 0 || kseg <= 0 || kseg % 128 || k <= 0 || k % kseg || (lda & 1) || (ldb & 1) ||
+      (kseg_stride & 1)) {
+    snprintf(g_err, sizeof(g_err), "mi_gp_gemm_nt_kseg: m, n, kseg multiples of 128, k a multiple of kseg, even strides");
+    return -1;
+  }
+  if (int r = ensure_init()) return r;
+  GemmParams p;
+  p.A = A; p.B = B; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.strideA = p.strideB = p.strideC = 0;
+  p.mt = m / 128; p.nt = n / 128; p.k = k; p.tri = tri; p.kmode = 0; p.alpha = alpha; p.beta = beta;
+  p.kseg = kseg; p.kseg_stride = kseg_stride;
+  if (small_below >= 0) p.small_below = small_below;
+  hipError_t e = launch_gemm_f64(p, 0, 0, 1, (hipStream_t)stream);
+  if (e != hipSuccess) return fail(e, "launch_gemm_f64");
+  return 0;
+}
+
 // ---------------------------------------------------------------- distributed-matrix building blocks
 static KernSpec make_spec(int d, int nkern, const int* kernel_ids, const int* ops) {
   KernSpec s;

@@ -4,6 +4,10 @@
 // the next panel's update + factorisation + staging on a side stream, and ONE panel-list GEMM launch for all owned
 // trailing panels on the main stream (round 2 issued one launch per owned panel from Python: 16 launches per step at 8
 // ranks, each below the 1024-tile threshold of the 128x128-tile kernel).
+// Round 4: a panel buffer is PIECE-major -- one contiguous piece per tile column (its rows x 128 doubles, then that
+// column's 128 x 128 leaf inverse) -- and a piece is staged as soon as its column is final (behind its strip), with an
+// event per piece, so that the caller can broadcast tile column c while columns c + 1 .. are still being factored.  The
+// GEMM kernels read such a buffer through their k-segmented operand form (GemmParams::kseg).
 #include <cstdio>
 #include <vector>
 #include "migp_kernels.h"
@@ -67,14 +71,20 @@ struct mi_gp_shard {
   int4* table_dev = nullptr;
   double* dinv_dev = nullptr;  // pwt leaf inverses of the panel being factored
   hipEvent_t ev_ready = nullptr, ev_staged = nullptr, ev_side_done = nullptr, ev_bulk = nullptr;
+  std::vector<hipEvent_t> ev_piece;  // recorded behind the staging of tile column c of the panel being factored
   bool staged_pending = false, ready_valid = false, bulk_valid = false;
   int bulk_one_per_cu = 1;
   int split_tiles = 2048;  // option 4: tiles of a bulk update that run one workgroup per CU beside this rank's chain (0: all)
   int early_next = 1;  // option 2: update the panel this rank factors next step first and alone (see mi_gp_shard_step)
+  int rest_from = -1;  // first column first: the panel whose update of tile columns 1.. of the panel being factored is still due
+  int pipelined = 2;   // option 5: a chain on the main stream stages each tile column behind its strip (0: behind the whole panel);
+                       // 2: and the previous panel's update takes tile column 0 first, so that it is final -- and leaves -- early
   int chain_on_main = 0;  // option 3: the owner chain runs on the main stream ahead of the bulk update (default: world > 1)
   int prof = 0;
   std::vector<hipEvent_t> pev;  // per step: side e0..e3 (before update, after update, after factor, after stage), main b0, b1
   std::vector<unsigned char> pmask;
+  std::vector<hipEvent_t> ppiece;  // per step and tile column: behind the staging of that piece (option 1)
+  int prof_step = -1;              // the step whose chain is being enqueued (row npan: panel 0 in begin)
   char err[256] = "";
 };
 
@@ -104,7 +114,9 @@ extern "C" int mi_gp_shard_destroy(mi_gp_shard* s) {
   if (s->ev_staged) (void)hipEventDestroy(s->ev_staged);
   if (s->ev_side_done) (void)hipEventDestroy(s->ev_side_done);
   if (s->ev_bulk) (void)hipEventDestroy(s->ev_bulk);
+  for (auto& e : s->ev_piece) if (e) (void)hipEventDestroy(e);
   for (auto& e : s->pev) if (e) (void)hipEventDestroy(e);
+  for (auto& e : s->ppiece) if (e) (void)hipEventDestroy(e);
   delete s;
   return 0;
 }
@@ -134,8 +146,8 @@ extern "C" int mi_gp_shard_create(const mi_gp_shard_config* cfg, mi_gp_shard** o
   for (int j = cfg->rank; j < s->npan; j += cfg->world) s->own.push_back(j);
   s->nown = (int)s->own.size();
   s->chain_on_main = cfg->world > 1 ? 1 : 0;
-  if (cfg->ldk < (long)std::max(s->nown, 1) * s->pw || cfg->ldp < s->pw) {
-    snprintf(g_shard_err, sizeof(g_shard_err), "mi_gp_shard_create: ldk must hold the %d owned panels of %d columns, ldp one panel",
+  if (cfg->ldk < (long)std::max(s->nown, 1) * s->pw || cfg->ldp < (long)(s->np + 256) * 128) {
+    snprintf(g_shard_err, sizeof(g_shard_err), "mi_gp_shard_create: ldk must hold the %d owned panels of %d columns, ldp one piece ((np + 256) * 128 doubles)",
              s->nown, s->pw);
     delete s;
     return -1;
@@ -155,6 +167,8 @@ extern "C" int mi_gp_shard_create(const mi_gp_shard_config* cfg, mi_gp_shard** o
   if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_staged, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_side_done, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_bulk, hipEventDisableTiming);
+  s->ev_piece.assign(s->pwt, nullptr);
+  for (int c = 0; c < s->pwt && e == hipSuccess; ++c) e = hipEventCreateWithFlags(&s->ev_piece[c], hipEventDisableTiming);
   if (e == hipSuccess && ensure_kernel_attributes() != 0) e = hipErrorUnknown;
   if (e != hipSuccess) {
     snprintf(g_shard_err, sizeof(g_shard_err), "mi_gp_shard_create: %s", hipGetErrorString(e));
@@ -174,6 +188,7 @@ extern "C" int mi_gp_shard_set_option(mi_gp_shard* s, int what, int value) {
   else if (what == 2) s->early_next = value ? 1 : 0;
   else if (what == 3) s->chain_on_main = value ? 1 : 0;
   else if (what == 4) s->split_tiles = value;
+  else if (what == 5) s->pipelined = value < 0 ? 0 : value > 2 ? 2 : value;
   else { snprintf(s->err, sizeof(s->err), "mi_gp_shard_set_option: unknown option %d", what); return -1; }
   return 0;
 }
@@ -192,33 +207,44 @@ static hipError_t prof_mark(mi_gp_shard* s, int step, int slot, hipStream_t st) 
   return hipEventRecord(ev, st);
 }
 
-// panel j (owned) of K -> buf: rows r0 .. np + 127, then the leaf inverses in the 128 rows behind them
-static hipError_t stage_panel(mi_gp_shard* s, int j, int li, double* buf, hipStream_t st) {
-  const int w = panel_w(s, j), r0 = j * s->pw, rows = s->np + 128 - r0;
-  const double* src = s->cfg.K_dev + (long)r0 * s->cfg.ldk + (long)li * s->pw;
-  const long total = (long)rows * (w * 64);
+// tile column c of panel j (owned) of K -> piece c of buf: rows r0 .. np + 127 at row stride 128, then the column's leaf inverse
+static hipError_t stage_piece(mi_gp_shard* s, int j, int li, int c, double* buf, hipStream_t st) {
+  const int r0 = j * s->pw, rows = s->np + 128 - r0;
+  const double* src = s->cfg.K_dev + (long)r0 * s->cfg.ldk + (long)li * s->pw + (long)c * 128;
+  double* dst = buf + (long)c * s->cfg.ldp;
+  const long total = (long)rows * 64;
   int blocks = (int)std::min<long>((total + 255) / 256, 4096);
-  copy_panel_kernel<<<blocks, 256, 0, st>>>(buf, s->cfg.ldp, src, s->cfg.ldk, rows, w * 64);
+  copy_panel_kernel<<<blocks, 256, 0, st>>>(dst, 128, src, s->cfg.ldk, rows, 64);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  return hipMemcpyAsync(buf + (long)rows * s->cfg.ldp, s->dinv_dev, sizeof(double) * MINV_ELEMS * (size_t)w,
-                        hipMemcpyDeviceToDevice, st);
+  e = hipMemcpyAsync(dst + (long)rows * 128, s->dinv_dev + (size_t)c * MINV_ELEMS, sizeof(double) * MINV_ELEMS,
+                     hipMemcpyDeviceToDevice, st);
+  if (e != hipSuccess) return e;
+  if (s->prof && s->prof_step >= 0) {
+    const size_t need = (size_t)(s->npan + 1) * s->pwt;
+    if (s->ppiece.size() < need) s->ppiece.resize(need, nullptr);
+    hipEvent_t& pe = s->ppiece[(size_t)s->prof_step * s->pwt + c];
+    if (!pe) {
+      e = hipEventCreate(&pe);
+      if (e != hipSuccess) return e;
+    }
+    e = hipEventRecord(pe, st);
+    if (e != hipSuccess) return e;
+  }
+  return hipEventRecord(s->ev_piece[c], st);
 }
 
-static hipError_t factor_panel(mi_gp_shard* s, int j, int li, hipStream_t st) {
-  const int w = panel_w(s, j), r0 = j * s->pw;
-  double* A = s->cfg.K_dev + (long)r0 * s->cfg.ldk + (long)li * s->pw;
-  return chol_panel_blocks(A, s->cfg.ldk, (s->np + 128 - r0) / 128, w, s->dinv_dev, s->cfg.info_dev, r0, st);
-}
-
-// owned panel jt (local index li) -= P_j[rows >= jt] P_j[rows of jt]^T with panel j in buf
-static hipError_t update_panel(mi_gp_shard* s, int jt, int li, int j, const double* buf, hipStream_t st) {
-  const int wt = panel_w(s, jt), wj = panel_w(s, j), rt = jt * s->pw;
+// owned panel jt (local index li) -= P_j[rows >= jt] P_j[rows of jt]^T with panel j in buf; cn > 0: only tile columns
+// [cb, cb + cn) of the panel (their trapezoid starts cb tile rows further down)
+static hipError_t update_panel(mi_gp_shard* s, int jt, int li, int j, const double* buf, hipStream_t st, int cb = 0, int cn = 0) {
+  const int wt = cn > 0 ? cn : panel_w(s, jt), wj = panel_w(s, j), rt = jt * s->pw + cb * 128;
   GemmParams p;
-  p.A = buf + (long)(rt - j * s->pw) * s->cfg.ldp;
+  p.A = buf + (long)(rt - j * s->pw) * 128;  // piece-major buffer: rows 128 doubles apart, tile column c at c * ldp
   p.B = p.A;
-  p.C = s->cfg.K_dev + (long)rt * s->cfg.ldk + (long)li * s->pw;
-  p.lda = p.ldb = s->cfg.ldp;
+  p.C = s->cfg.K_dev + (long)rt * s->cfg.ldk + (long)li * s->pw + (long)cb * 128;
+  p.lda = p.ldb = 128;
+  p.kseg = 128;
+  p.kseg_stride = s->cfg.ldp;
   p.ldc = s->cfg.ldk;
   p.strideA = p.strideB = p.strideC = 0;
   p.mt = (s->np + 128 - rt) / 128;
@@ -232,6 +258,58 @@ static hipError_t update_panel(mi_gp_shard* s, int jt, int li, int j, const doub
   return launch_gemm_f64(p, 0, 0, 1, st);
 }
 
+// factor tile columns [c0, c0 + w) of owned panel j (recursive halving, as migp::chol_panel_blocks) and stage every
+// column behind its strip
+static hipError_t factor_stage_rec(mi_gp_shard* s, int j, int li, double* A, int ntr, int c0, int w, double* buf, hipStream_t st) {
+  const long lda = s->cfg.ldk;
+  hipError_t e;
+  if (w == 1) {
+    double* blk = A + (long)c0 * 128 * lda + (long)c0 * 128;
+    double* dinv = s->dinv_dev + (size_t)c0 * MINV_ELEMS;
+    e = launch_potrf_leaf128(blk, lda, dinv, j * s->pw + c0 * 128, s->cfg.info_dev, st);
+    if (e != hipSuccess) return e;
+    e = launch_trsm_strip128(dinv, blk + 128 * lda, lda, (ntr - c0 - 1) * 128, st);
+    if (e != hipSuccess) return e;
+    e = stage_piece(s, j, li, c0, buf, st);
+    if (e == hipSuccess && c0 == 0 && s->rest_from >= 0) {
+      // first column first: the previous panel's update of tile columns 1.. was held back so that column 0 could be
+      // factored, staged and SENT before it
+      const int jp = s->rest_from;
+      s->rest_from = -1;
+      if (panel_w(s, j) > 1) e = update_panel(s, j, li, jp, s->cfg.P_dev[jp & 1], st, 1, panel_w(s, j) - 1);
+    }
+    return e;
+  }
+  const int w1 = w / 2, w2 = w - w1;
+  e = factor_stage_rec(s, j, li, A, ntr, c0, w1, buf, st);
+  if (e != hipSuccess) return e;
+  GemmParams p;
+  p.A = A + (long)(c0 + w1) * 128 * lda + (long)c0 * 128;
+  p.B = p.A;
+  p.C = A + (long)(c0 + w1) * 128 * lda + (long)(c0 + w1) * 128;
+  p.lda = p.ldb = p.ldc = lda;
+  p.strideA = p.strideB = p.strideC = 0;
+  p.mt = ntr - c0 - w1; p.nt = w2; p.k = w1 * 128; p.tri = 1; p.kmode = 0; p.alpha = -1.0; p.beta = 1.0;
+  e = launch_gemm_f64(p, 0, 0, 1, st);
+  if (e != hipSuccess) return e;
+  return factor_stage_rec(s, j, li, A, ntr, c0 + w1, w2, buf, st);
+}
+
+// Factor owned panel j and stage it into buf.  before_stage == nullptr: PIPELINED, every tile column is staged (and its
+// event recorded) right behind its strip.  Otherwise the buffer may still be the operand of main-stream updates that run
+// beside this chain: the whole panel is factored first, then the stream waits for `before_stage` and stages the pieces.
+static hipError_t factor_stage_panel(mi_gp_shard* s, int j, int li, double* buf, bool pipelined, hipEvent_t before_stage,
+                                     hipStream_t st) {
+  const int w = panel_w(s, j), r0 = j * s->pw;
+  double* A = s->cfg.K_dev + (long)r0 * s->cfg.ldk + (long)li * s->pw;
+  s->prof_step = j == 0 ? s->npan : j - 1;  // the step that produces panel j
+  if (pipelined) return factor_stage_rec(s, j, li, A, (s->np + 128 - r0) / 128, 0, w, buf, st);
+  hipError_t e = chol_panel_blocks(A, s->cfg.ldk, (s->np + 128 - r0) / 128, w, s->dinv_dev, s->cfg.info_dev, r0, st);
+  if (e == hipSuccess && before_stage) e = hipStreamWaitEvent(st, before_stage, 0);
+  for (int c = 0; c < w && e == hipSuccess; ++c) e = stage_piece(s, j, li, c, buf, st);
+  return e;
+}
+
 // every owned panel with local index >= li0 in ONE launch (panel-list mode)
 static hipError_t update_bulk(mi_gp_shard* s, int li0, int j, const double* buf, int one_per_cu, hipStream_t st) {
   if (li0 >= s->nown) return hipSuccess;
@@ -239,7 +317,9 @@ static hipError_t update_bulk(mi_gp_shard* s, int li0, int j, const double* buf,
   p.A = buf;
   p.B = buf;
   p.C = s->cfg.K_dev;
-  p.lda = p.ldb = s->cfg.ldp;
+  p.lda = p.ldb = 128;
+  p.kseg = 128;
+  p.kseg_stride = s->cfg.ldp;
   p.ldc = s->cfg.ldk;
   p.strideA = p.strideB = p.strideC = 0;
   p.mt = p.nt = 0;
@@ -275,6 +355,7 @@ extern "C" int mi_gp_shard_begin(mi_gp_shard* s, int noise_form, void* main_stre
   hipStream_t M = (hipStream_t)main_stream;
   SCK(hipSetDevice(s->cfg.device), "hipSetDevice");
   s->staged_pending = s->ready_valid = s->bulk_valid = false;
+  s->rest_from = -1;
   if (s->prof) s->pmask.assign(s->npan + 1, 0);
   const int n = s->cfg.n, d = s->cfg.d;
   bool info_reset = false;
@@ -291,9 +372,8 @@ extern "C" int mi_gp_shard_begin(mi_gp_shard* s, int noise_form, void* main_stre
   if (!info_reset) SCK(hipMemsetAsync(s->cfg.info_dev, 0x7f, sizeof(int), M), "info reset");
   if (s->cfg.rank == 0 && s->nown > 0) {  // owner of panel 0
     SCK(prof_mark(s, s->npan, 1, M), "event");
-    SCK(factor_panel(s, 0, 0, M), "factor panel 0");
+    SCK(factor_stage_panel(s, 0, 0, s->cfg.P_dev[0], true, nullptr, M), "factor + stage panel 0");
     SCK(prof_mark(s, s->npan, 2, M), "event");
-    SCK(stage_panel(s, 0, 0, s->cfg.P_dev[0], M), "stage panel 0");
     SCK(prof_mark(s, s->npan, 3, M), "event");
   }
   return 0;
@@ -324,16 +404,18 @@ extern "C" int mi_gp_shard_step(mi_gp_shard* s, int j, void* main_stream, void* 
     // rank's bulk update, is what every other rank waits for
     const int li = (jn - rank) / world;
     SCK(prof_mark(s, j, 0, M), "event");
-    SCK(update_panel(s, jn, li, j, buf, M), "update next panel");
+    if (s->pipelined == 2 && panel_w(s, jn) > 1) {
+      SCK(update_panel(s, jn, li, j, buf, M, 0, 1), "update next panel, first tile column");
+      s->rest_from = j;  // the other columns follow behind column 0's leaf, strip and staging (factor_stage_rec)
+    } else {
+      SCK(update_panel(s, jn, li, j, buf, M), "update next panel");
+    }
     SCK(prof_mark(s, j, 1, M), "event");
-    SCK(factor_panel(s, jn, li, M), "factor next panel");
+    SCK(factor_stage_panel(s, jn, li, s->cfg.P_dev[jn & 1], s->pipelined != 0, nullptr, M), "factor + stage next panel");
     SCK(prof_mark(s, j, 2, M), "event");
-    SCK(stage_panel(s, jn, li, s->cfg.P_dev[jn & 1], M), "stage next panel");
     SCK(prof_mark(s, j, 3, M), "event");
-    // the caller broadcasts the staged panel under side_stream: ordered behind the staging, NOT behind the bulk update
-    // that follows on the main stream
-    SCK(hipEventRecord(s->ev_staged, M), "record staged");
-    SCK(hipStreamWaitEvent(S, s->ev_staged, 0), "side waits staged");
+    // the caller broadcasts the pieces under side_stream, each behind mi_gp_shard_wait_piece: ordered behind that piece's
+    // staging, NOT behind the later columns' factorisation or the bulk update that follows on the main stream
   } else if (jn < s->npan && jn % world == rank) {
     const int li = (jn - rank) / world;
     // the previous step recorded ev_ready right behind its update of panel jn; without one (first step) everything
@@ -343,11 +425,9 @@ extern "C" int mi_gp_shard_step(mi_gp_shard* s, int j, void* main_stream, void* 
     SCK(prof_mark(s, j, 0, S), "event");
     SCK(update_panel(s, jn, li, j, buf, S), "update next panel");
     SCK(prof_mark(s, j, 1, S), "event");
-    SCK(factor_panel(s, jn, li, S), "factor next panel");
+    // P[jn % 2] was the operand of the previous step's main-stream updates, which run beside this chain: staged at the end
+    SCK(factor_stage_panel(s, jn, li, s->cfg.P_dev[jn & 1], false, s->bulk_valid ? s->ev_bulk : nullptr, S), "factor + stage next panel");
     SCK(prof_mark(s, j, 2, S), "event");
-    // P[jn % 2] was the operand of the previous step's main-stream updates
-    if (s->bulk_valid) SCK(hipStreamWaitEvent(S, s->ev_bulk, 0), "wait bulk");
-    SCK(stage_panel(s, jn, li, s->cfg.P_dev[jn & 1], S), "stage next panel");
     SCK(prof_mark(s, j, 3, S), "event");
     SCK(hipEventRecord(s->ev_staged, S), "record staged");
     s->staged_pending = true;
@@ -374,6 +454,13 @@ extern "C" int mi_gp_shard_step(mi_gp_shard* s, int j, void* main_stream, void* 
   return 0;
 }
 
+extern "C" int mi_gp_shard_wait_piece(mi_gp_shard* s, int c, void* stream) {
+  if (!s || c < 0 || c >= s->pwt) return -1;
+  SCK(hipSetDevice(s->cfg.device), "hipSetDevice");
+  SCK(hipStreamWaitEvent((hipStream_t)stream, s->ev_piece[c], 0), "wait piece");
+  return 0;
+}
+
 extern "C" int mi_gp_shard_finish(mi_gp_shard* s, void* main_stream, void* side_stream) {
   if (!s) return -1;
   hipStream_t M = (hipStream_t)main_stream, S = (hipStream_t)side_stream;
@@ -384,6 +471,25 @@ extern "C" int mi_gp_shard_finish(mi_gp_shard* s, void* main_stream, void* side_
   shard_reduce_kernel<<<1, 256, 0, M>>>(s->cfg.K_dev, s->cfg.ldk, s->table_dev, s->nown, s->cfg.n, s->np, s->cfg.out_dev);
   SCK(hipGetLastError(), "shard_reduce");
   return 0;
+}
+
+// out[step * panel_tiles + c] = ms from the start of step `step`'s chain (its update of the next panel; row npanels:
+// the factorisation of panel 0) to the end of the staging of tile column c (option 1; 0 where there was none)
+extern "C" int mi_gp_shard_piece_times(mi_gp_shard* s, double* out, int max_steps) {
+  if (!s || !out) return -1;
+  const int rows = std::min(max_steps, s->npan + 1);
+  for (int i = 0; i < s->pwt * rows; ++i) out[i] = 0.0;
+  if (s->pev.empty() || s->ppiece.empty()) return 0;
+  for (int j = 0; j < rows; ++j) {
+    const int slot0 = j == s->npan ? 1 : 0;
+    if (!((s->pmask[j] >> slot0) & 1)) continue;
+    for (int c = 0; c < s->pwt; ++c) {
+      hipEvent_t pe = s->ppiece[(size_t)j * s->pwt + c];
+      float ms = 0.f;
+      if (pe && hipEventElapsedTime(&ms, s->pev[(size_t)j * 6 + slot0], pe) == hipSuccess && ms > 0.f) out[j * s->pwt + c] = ms;
+    }
+  }
+  return rows;
 }
 
 extern "C" int mi_gp_shard_times(mi_gp_shard* s, double* out, int max_steps) {

@@ -225,6 +225,9 @@ __global__ __launch_bounds__(vb::NT_B, 2) void gemm_f64_kernel_b(GemmParams p) {
   const char* Bg = reinterpret_cast<const char*>(B_KMAJOR ? B + (long)kbeg * p.ldb + j0 : B + (long)j0 * p.ldb + kbeg);
   const long stepA = (A_KMAJOR ? (long)BKB * p.lda : (long)BKB) * 8;
   const long stepB = (B_KMAJOR ? (long)BKB * p.ldb : (long)BKB) * 8;
+  // k-segmented operands: the step INTO chunk n is a jump to the next segment's base when n is a multiple of kseg / BKB
+  const int segmask = p.kseg > 0 ? p.kseg / BKB - 1 : 0x7fffffff;
+  const long segjump = (p.kseg_stride - (long)(p.kseg - BKB)) * 8;
   char* Asb = reinterpret_cast<char*>(As);
   char* Bsb = reinterpret_cast<char*>(Bs);
   // Global -> register prefetch runs TWO chunks ahead (register set c & 1 holds chunk c until it is written to
@@ -283,8 +286,9 @@ __global__ __launch_bounds__(vb::NT_B, 2) void gemm_f64_kernel_b(GemmParams p) {
     constexpr int lastc = decltype(LASTC)::value;  // 0: inside the loop; 1 / 2: second-to-last / last chunk
     constexpr int boff = s * OPER_B;
     const bool adv = (c + 2 < nchunk);
-    Ag += adv ? stepA : 0;
-    Bg += adv ? stepB : 0;
+    const bool seg = ((c + 2) & segmask) == 0;
+    Ag += adv ? (seg ? segjump : stepA) : 0;
+    Bg += adv ? (seg ? segjump : stepB) : 0;
 #pragma unroll
     for (int kk = 0; kk < BKB / 4; ++kk) {
       const int cur = kk & 1;
@@ -487,6 +491,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel_s(GemmParams p) {
   const char* Bg = reinterpret_cast<const char*>(B_KMAJOR ? B + (long)kbeg * p.ldb + j0 : B + (long)j0 * p.ldb + kbeg);
   const long stepA = (A_KMAJOR ? (long)BKS * p.lda : (long)BKS) * 8;
   const long stepB = (B_KMAJOR ? (long)BKS * p.ldb : (long)BKS) * 8;
+  const int segmask = p.kseg > 0 ? p.kseg / BKS - 1 : 0x7fffffff;  // k-segmented operands, as in the 128x128-tile kernel
+  const long segjump = (p.kseg_stride - (long)(p.kseg - BKS)) * 8;
   char* Asb = reinterpret_cast<char*>(As);
   char* Bsb = reinterpret_cast<char*>(Bs);
   // Pipeline (chunk = 16 k = 16 MFMAs per wave, 0.43 us): chunk c is requested from global memory during chunk c - 4
@@ -499,8 +505,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel_s(GemmParams p) {
   double2_t ra[NB][NQS], rb[NB][NQS];
   auto advance = [&](int next_chunk) {  // chunks beyond the last are redundant reloads of the last one, never consumed
     const bool adv = next_chunk < nchunk;
-    Ag += adv ? stepA : 0;
-    Bg += adv ? stepB : 0;
+    const bool seg = (next_chunk & segmask) == 0;
+    Ag += adv ? (seg ? segjump : stepA) : 0;
+    Bg += adv ? (seg ? segjump : stepB) : 0;
   };
   if (nchunk > 0) {
 #pragma unroll
@@ -649,6 +656,8 @@ hipError_t launch_gemm_f64(const GemmParams& p_in, int opA_kmajor, int opB_kmajo
   // 8192 x 1024: 253 vs 264 us).  Wide trapezoids (the bulk updates) keep the band-column-major order of section 5.1.
   if (p.tri && !p.pl && p.nt <= NARROW_TRAPEZOID_COLS) p.band = 0;
   if (!(p.tri && !p.pl && p.kmode == 0 && p.fc > 0 && p.fc < p.nt)) p.fc = 0;
+  if (p.kseg != 0 && (p.kseg < 0 || p.kseg % 128 || p.kmode != 0 || opA_kmajor || opB_kmajor || p.k % p.kseg))
+    return hipErrorInvalidValue;  // k-segments: whole tile columns, the NT form, uniform k
   const int nblk = tile_count(p);
   if (nblk <= 0 || batch <= 0) return hipSuccess;
   const bool small = gemm_uses_small_tiles(p, batch);

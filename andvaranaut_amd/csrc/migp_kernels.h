@@ -51,6 +51,11 @@ struct GemmParams {
   // row, like a narrow trapezoid), then the rest in the banded order.  With a sub-range launch over a prefix this lets the
   // driver finish the NEXT super-panel's columns ahead of the rest of a trailing update inside ONE enumeration.
   int fc = 0;
+  // k-segmented operands (NT form, kmode 0 only): A and B are stored as k-segments of `kseg` columns (a multiple of 128),
+  // segment g of an operand at base + g * kseg_stride doubles, rows lda / ldb apart inside a segment.  The sharded driver's
+  // panel buffer is laid out this way (one contiguous piece per tile column, broadcast as soon as it is final).  0: one segment.
+  int kseg = 0;
+  long kseg_stride = 0;
   // set by the launcher for that second launch: 64x64 tile 4 e + quadrant belongs to 128x128 tile sub_base + e of the
   // parent enumeration (sub_mt x sub_nt tiles of 128); -1: off
   int sub_base = -1, sub_mt = 0, sub_nt = 0;

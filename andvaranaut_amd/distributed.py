@@ -3,7 +3,10 @@ row; BASELINE config 4): 1-D block-cyclic distribution of 512- or 1024-column su
 over the ranks, right-looking Cholesky in which the owner factors a panel and broadcasts it
 (torch.distributed: RCCL over xGMI with backend "nccl") and every rank updates the panels it owns.
 One look-ahead step: the owner of the next panel updates and factors it first and its broadcast is
-posted before the bulk updates, so the transfer overlaps them.
+posted before the bulk updates, so the transfer overlaps them.  The broadcast is pipelined: a panel buffer is
+piece-major (one contiguous piece per 128-column tile column) and the owner sends tile column c as soon as its strip is
+done, while columns c + 1 .. are still being factored -- only the last piece's transfer is exposed (include/mi_gp.h,
+"sharded factorisation"); the owner itself never waits for its own sends, only before it re-uses their buffer.
 
 Only the exchange step is a collective (one broadcast per panel, two scalars all-reduced at the
 end); assembly is local (X is replicated, 8*N*d bytes).  All arithmetic runs in the same HIP kernels
@@ -30,7 +33,7 @@ from . import _lib
 from .backend import parse_kernel
 
 MINV = 128 * 128  # doubles per leaf inverse (mi_gp_chol_panel writes one per 128-column tile)
-DINV_ROWS = 128  # pwt * MINV leaf-inverse doubles appended to a broadcast panel (flat view of 128 rows of pw + 16 doubles)
+DINV_ROWS = 128  # the tile column's leaf inverse rides behind its rows in a piece (128 rows of 128 doubles)
 
 
 def panel_tiles(ntc, world):
@@ -43,6 +46,17 @@ def panel_tiles(ntc, world):
     if world >= 4:
         return 4
     return 8 if ntc >= 32 * world else 4
+
+
+class _Works:
+    """The work handles of one panel's pieces: wait() orders the current stream behind all of them."""
+
+    def __init__(self, works):
+        self.works = [w for w in works if w is not None]
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
 
 
 class _Arrived:
@@ -100,7 +114,8 @@ class DistGP:
             self.X_t = torch.from_numpy(X).to(self.dev)
             self.y_t = torch.from_numpy(y).to(self.dev)
             self.K = torch.zeros((rows, self.ld), dtype=torch.float64, device=self.dev)
-            self.P = [torch.zeros((rows + DINV_ROWS, self.ldbuf), dtype=torch.float64, device=self.dev) for _ in range(2)]
+            # piece-major panel buffers: piece c = tile column c of a panel (its rows at a stride of 128, then its leaf inverse)
+            self.P = [torch.zeros((self.pwt, rows + DINV_ROWS, 128), dtype=torch.float64, device=self.dev) for _ in range(2)]
             self.theta_t = torch.zeros(self.ntheta, dtype=torch.float64, device=self.dev)
             self.info = torch.zeros(4, dtype=torch.int32, device=self.dev)
             self.out = torch.zeros(16, dtype=torch.float64, device=self.dev)
@@ -117,7 +132,7 @@ class DistGP:
             cfg.kernel_ids[i], cfg.ops[i] = self.kids[i], self.opids[i]
         cfg.panel_tiles, cfg.world, cfg.rank, cfg.device = self.pwt, self.world, self.rank, self.dev.index
         cfg.X_dev, cfg.y_dev, cfg.K_dev, cfg.ldk = self.X_t.data_ptr(), self.y_t.data_ptr(), self.K.data_ptr(), self.ld
-        cfg.P_dev[0], cfg.P_dev[1], cfg.ldp = self.P[0].data_ptr(), self.P[1].data_ptr(), self.ldbuf
+        cfg.P_dev[0], cfg.P_dev[1], cfg.ldp = self.P[0].data_ptr(), self.P[1].data_ptr(), self.P[0].stride(0)
         cfg.theta_dev, cfg.info_dev, cfg.out_dev = self.theta_t.data_ptr(), self.info.data_ptr(), self.out.data_ptr()
         self.sh = ctypes.c_void_p()
         r = self.lib.mi_gp_shard_create(ctypes.byref(cfg), ctypes.byref(self.sh))
@@ -158,7 +173,9 @@ class DistGP:
     def set_option(self, what, value):
         """mi_gp_shard_set_option: 0 bulk updates one workgroup per CU beside the chain, 1 per-step events, 2 early update,
         3 chain on the main stream ahead of the bulk update (default on several ranks), 4 tiles of a bulk update that run one
-        workgroup per CU beside this rank's chain, the rest two per CU (default 2048, 0: all)."""
+        workgroup per CU beside this rank's chain, the rest two per CU (default 2048, 0: all), 5 a chain on the main stream
+        stages (and this class sends) every tile column behind its strip (1; 2, the default: the first column is also
+        updated first and alone; 0: the panel behind its last column)."""
         self._scheck(self.lib.mi_gp_shard_set_option(self.sh, int(what), int(value)), "mi_gp_shard_set_option")
 
     def step_times(self):
@@ -167,6 +184,13 @@ class DistGP:
         buf = (ctypes.c_double * (4 * (self.npan + 1)))()
         n = self.lib.mi_gp_shard_times(self.sh, buf, self.npan + 1)
         return np.array(buf[: 4 * max(n, 0)]).reshape(-1, 4)
+
+    def piece_times(self):
+        """[npan + 1][pwt] ms from the start of a step's chain to the end of the staging of each tile column of the panel
+        it produces (needs set_option(1, 1)); row npan: panel 0."""
+        buf = (ctypes.c_double * (self.pwt * (self.npan + 1)))()
+        n = self.lib.mi_gp_shard_piece_times(self.sh, buf, self.npan + 1)
+        return np.array(buf[: self.pwt * max(n, 0)]).reshape(-1, self.pwt)
 
     def set_factor_source(self, K_full, ld_full):
         """emulation: a complete factor (padded n + 128 rows: L in the lower triangle, beta^T in row np) that the panels
@@ -188,7 +212,13 @@ class DistGP:
             ms, ss = ctypes.c_void_p(main.cuda_stream), ctypes.c_void_p(self.side.cuda_stream)
             self.theta_t.copy_(torch.from_numpy(theta))
             self._scheck(lib.mi_gp_shard_begin(sh, noise_form, ms, ss), "mi_gp_shard_begin")
+            # sends[b]: the broadcasts this rank posted as the OWNER out of buffer b.  The owner has the panel already: it
+            # never waits for them on its compute streams, only before it stages into that buffer again (a receive into it
+            # is ordered behind them on the transport's own stream anyway).
+            sends = [None, None]
             work = self._exchange(0)  # panel 0 was staged on the main stream by its owner
+            if owner(0) == self.rank:
+                sends[0], work = work, None
             # the stream the owner's chain runs on (mi_gp_shard option 3): the side stream beside the bulk update on one
             # rank, the main stream ahead of it on several
             chain_stream = main if lib.mi_gp_shard_chain_stream(sh) == 1 else self.side
@@ -201,13 +231,23 @@ class DistGP:
                         with torch.cuda.stream(self.side):
                             work.wait()  # ... and so does the side stream, whose chain reads it first
                 work = None
+                if chain_stream is not main and owner(j) == self.rank:
+                    # this rank's side stream produced panel j: its chain READ P[(j - 1) % 2], the buffer the next exchange
+                    # (posted under the main stream just below) writes.  Nothing else orders that write behind the read.
+                    main.wait_stream(self.side)
+                if mine and sends[jn % 2] is not None:
+                    with torch.cuda.stream(chain_stream):
+                        sends[jn % 2].wait()  # this step stages panel jn into the buffer those sends read
+                    sends[jn % 2] = None
                 if jn < self.npan and not mine:
                     work = self._exchange(jn)  # posted before this step's launches so that it overlaps them
+                    sends[jn % 2] = None  # (ordered behind this rank's earlier sends out of that buffer by the transport)
                 self._scheck(lib.mi_gp_shard_step(sh, j, ms, ss), "mi_gp_shard_step")
                 if mine:
                     with torch.cuda.stream(self.side):
-                        # behind the staging (the side stream is ordered after it in both modes), not behind the bulk update
-                        work = self._exchange(jn)
+                        # piece by piece behind its staging (mi_gp_shard_wait_piece), not behind the later columns'
+                        # factorisation or the bulk update
+                        sends[jn % 2] = self._exchange(jn)
                 if _keep:
                     self._keep_panel(j, self.P[j % 2])
                     if chain_stream is not main:
@@ -217,6 +257,9 @@ class DistGP:
                         kept = torch.cuda.Event()
                         kept.record(main)
                         self.side.wait_event(kept)
+            for b in range(2):
+                if sends[b] is not None:
+                    sends[b].wait()  # the next evaluation re-uses the buffers
             self._scheck(lib.mi_gp_shard_finish(sh, ms, ss), "mi_gp_shard_finish")
             # local pieces of sum log L_ii and |beta|^2, then one small all-reduce
             acc = self.out[1:3].clone()
@@ -234,41 +277,44 @@ class DistGP:
         return -0.5 * self.n * math.log(2.0 * math.pi) - 0.5 * quad - logdet
 
     def _exchange(self, j):
-        """Post the exchange of panel j under the current stream: the RCCL broadcast from its owner, or -- emulating
-        another rank's panel -- a copy from the complete factor on the stand-in link stream.  Returns something with
-        .wait() (makes the then-current stream wait for the panel) or None when there is nothing to wait for."""
+        """Post the exchange of panel j under the current stream, one piece (tile column) at a time: the RCCL broadcasts
+        from its owner -- who orders each behind that piece's staging -- or, emulating another rank's panel, copies from
+        the complete factor on the stand-in link stream.  Returns something with .wait() (makes the then-current stream
+        wait for the whole panel) or None when there is nothing to wait for."""
         if self.collective:
             return self._bcast(j)
-        if self.emulate:
-            if j % self.world != self.rank:
-                return self._standin(j)
-            # this rank's own panel: in a real run its broadcast completes behind the staging on the stream it was posted
-            # under, and work.wait() orders the main stream (and the next exchange into the partner buffer) behind it
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.dev))
-            return _Arrived(self.dev, ev)
-        return None
+        if self.emulate and j % self.world != self.rank:
+            return self._standin(j)
+        return None  # this rank's own panel: nothing arrives, and nothing is sent in an emulation
+
+    def _piece_rows(self, j):
+        return self.np_ + 128 - j * self.pw  # rows of panel j in a piece (the y^T block included)
 
     def _standin(self, j):
         src, _ = self.source
-        w, r0 = self._w(j), j * self.pw
-        rows = self.np_ + 128 - r0
+        w, r0, rows = self._w(j), j * self.pw, self._piece_rows(j)
         cur = torch.cuda.current_stream(self.dev)
         self.link.wait_stream(cur)  # like the transport: ordered behind the stream the exchange was posted under
         with torch.cuda.stream(self.link):
-            self.P[j % 2][:rows, : w * 128].copy_(src[r0: r0 + rows, r0: r0 + w * 128])
+            for c in range(w):
+                self.P[j % 2][c, :rows].copy_(src[r0: r0 + rows, r0 + c * 128: r0 + (c + 1) * 128])
             ev = torch.cuda.Event()
             ev.record(self.link)
-        self.bytes_broadcast += (rows + DINV_ROWS) * self.ldbuf * 8
+        self.bytes_broadcast += w * (rows + DINV_ROWS) * 128 * 8
         return _Arrived(self.dev, ev)
 
     def _bcast(self, j):
         if not self.collective:
             return None
-        rows = self.np_ + 128 - j * self.pw + DINV_ROWS
-        view = self.P[j % 2][:rows]  # contiguous leading rows of the panel buffer
-        self.bytes_broadcast += view.numel() * 8
-        return dist.broadcast(view, src=j % self.world, async_op=True)
+        src, rows = j % self.world, self._piece_rows(j) + DINV_ROWS
+        works = []
+        for c in range(self._w(j)):
+            view = self.P[j % 2][c, :rows]  # contiguous: the column's rows, then its leaf inverse
+            if src == self.rank:
+                self._scheck(self.lib.mi_gp_shard_wait_piece(self.sh, c, self._stream()), "mi_gp_shard_wait_piece")
+            self.bytes_broadcast += view.numel() * 8
+            works.append(dist.broadcast(view, src=src, async_op=True))
+        return _Works(works)
 
     # ------------------------------------------------------------------ gradient
     def _alloc_grad_buffers(self):
@@ -289,14 +335,13 @@ class DistGP:
             self.gslab = torch.zeros(self.ntheta, dtype=torch.float64, device=self.dev)
 
     def _keep_panel(self, j, buf):
-        w = self._w(j)
-        r0 = j * self.pw
-        rows = self.np_ - r0
-        self.Lf[r0:, r0: r0 + w * 128].copy_(buf[:rows, : w * 128])
-        self.dinv_f[j * self.pwt * MINV: (j * self.pwt + w) * MINV].copy_(
-            buf[rows + 128: rows + 128 + DINV_ROWS].view(-1)[: w * MINV])
-        nv = max(0, min(self.n - r0, w * 128))  # beta = L^-1 y rides in the first row of the panel's y block
-        self.beta_f[r0: r0 + nv].copy_(buf[rows, :nv])
+        w, r0, rows = self._w(j), j * self.pw, self._piece_rows(j)
+        for c in range(w):
+            c0 = r0 + c * 128
+            self.Lf[r0:, c0: c0 + 128].copy_(buf[c, : self.np_ - r0])
+            self.dinv_f[(j * self.pwt + c) * MINV: (j * self.pwt + c + 1) * MINV].copy_(buf[c, rows: rows + DINV_ROWS].reshape(-1))
+            nv = max(0, min(self.n - c0, 128))  # beta = L^-1 y rides in the first row of the piece's y block
+            self.beta_f[c0: c0 + nv].copy_(buf[c, self.np_ - r0, :nv])
 
     def _u_owned(self):
         """Rows of U = L^-T for the owned panels, stacked in ascending panel order in self.S: X L^T = (those rows of I).

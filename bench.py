@@ -243,16 +243,20 @@ def sharded_record(args, rank, world, dev, N, d, kernel, steps, warmup, grad=Fal
             rec["single_gpu_check"] = f"skipped: {type(e).__name__}: {e}"
     # the one-GPU rank emulation's prediction for this world size (tools/emulate_rank.py --curve), for the first hardware
     # run to be checked against: a model (measured per-rank compute and owner chain + bytes / link bandwidth), not a result
-    mfile = os.path.join(ROOT, "profiles", "r03_sharded_model.json")
+    mfile = os.path.join(ROOT, "profiles", "r04_sharded_model.json")
+    if not os.path.exists(mfile):
+        mfile = os.path.join(ROOT, "profiles", "r03_sharded_model.json")
     if not grad and os.path.exists(mfile):
         try:
             mj = json.load(open(mfile))
             if mj.get("N") == N and mj.get("d") == d:
                 for pr in mj.get("prediction", []):
                     # the model file holds both chain placements for world > 1; the driver's default is "ahead of the bulk update"
-                    if pr.get("world") == world and pr.get("panel_tiles") == gp_pwt and (world == 1 or pr.get("chain", "").startswith("on the main")):
+                    # ... sending each tile column behind its strip (the first such entry; the whole-panel send follows it)
+                    if (pr.get("world") == world and pr.get("panel_tiles") == gp_pwt and "predicted_ms_per_step" not in rec
+                            and (world == 1 or pr.get("chain", "").startswith("on the main"))):
                         rec["predicted_ms_per_step"] = pr["predicted_ms"]
-                        rec["prediction_source"] = "profiles/r03_sharded_model.json (one-GPU emulation of ranks + link model)"
+                        rec["prediction_source"] = f"profiles/{os.path.basename(mfile)} (one-GPU emulation of ranks + link model)"
         except Exception as e:  # noqa: BLE001
             rec["prediction_source"] = f"unreadable: {e}"
     return rec

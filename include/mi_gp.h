@@ -185,6 +185,14 @@ int mi_gp_gemm_f64_tuned(int transa, int transb, int m, int n, int k, double alp
                          const double* B_dev, long ldb, double beta, double* C_dev, long ldc, int tri, int kmode,
                          int small_below, int tail_small, int band, int one_per_cu, void* hip_stream);
 
+/* C = beta*C + alpha*A*B^T (tri as above) with both operands stored as k-segments: segment g (kseg columns, a multiple of
+ * 128) of A at A_dev + g * kseg_stride with rows lda apart, the same for B.  This is how the GEMM kernels read the sharded
+ * driver's piece-major panel buffers (one contiguous piece per tile column, sent as soon as it is final).  small_below < 0:
+ * the launcher's default. */
+int mi_gp_gemm_nt_kseg(int m, int n, int k, double alpha, const double* A_dev, long lda, const double* B_dev, long ldb,
+                       int kseg, long kseg_stride, double beta, double* C_dev, long ldc, int tri, int small_below,
+                       void* hip_stream);
+
 /* K(Xrows, Xcols) for one rectangular block of a (distributed) covariance: rows row0.. and columns
  * col0.. of the global matrix; noise + jitter go on the global diagonal, identity in the padding
  * (rows >= nrows / columns >= ncols of the padded block).  Same kernel as the single-GPU assembly
@@ -230,16 +238,20 @@ int mi_gp_grad_contract_block(int d, int nkern, const int* kernel_ids, const int
 /* ---- sharded factorisation, one call per panel step (SURVEY 8e second row; BASELINE config 4).  The covariance is
  * distributed over `world` ranks in 1-D block-cyclic column panels of panel_tiles * 128 columns (panel j belongs to rank
  * j % world); a rank stores its panels side by side (local column li * pw for its li-th panel) with GLOBAL rows.  The
- * exchange itself (one broadcast of P_dev[j % 2] per panel) stays with the caller (torch.distributed / RCCL); these
- * entries enqueue everything else of a step behind one call:
+ * exchange itself (one broadcast per tile column of the panel, out of P_dev[j % 2]) stays with the caller (torch.distributed /
+ * RCCL); these entries enqueue everything else of a step behind one call:
  *   begin : assemble the owned panels (+ their y^T rows); the owner of panel 0 factors it and stages it into P_dev[0]
  *   step j: panel j is complete in P_dev[j % 2] and visible to main_stream AND side_stream.  The owner of panel j+1 updates it with
  *           panel j, factors it and stages it into P_dev[(j+1) % 2] on side_stream (the caller broadcasts it under that
  *           stream); then ONE GEMM launch on main_stream updates every owned panel > j+1 (panel-list mode of the kernel)
  *   finish: main_stream waits for side_stream; out_dev[1] = sum log L_ii, out_dev[2] = sum beta_i^2 over the owned panels
- * A panel buffer holds rows r0 = j * pw .. np + 127 of the panel (np = padded n; rows np.. = the y^T block whose first
- * row becomes beta^T), then 128 more rows whose flat leading panel_tiles * 16384 doubles are the leaf inverses (the
- * sharded gradient needs them everywhere): (np + 256) rows x ldp >= pw + 16 doubles.
+ * A panel buffer is PIECE-major: piece c (tile column c of the panel) starts at P_dev[b] + c * ldp and holds rows
+ * r0 = j * pw .. np + 127 of that column at a row stride of 128 doubles (np = padded n; rows np.. = the y^T block whose
+ * first row becomes beta^T), then the column's 128 x 128 leaf inverse (the sharded gradient needs it everywhere):
+ * (np + 128 - r0 + 128) * 128 contiguous doubles = ONE broadcast; ldp >= (np + 256) * 128.  On several ranks the owner
+ * stages piece c right behind column c's strip (option 5) and the caller sends it -- mi_gp_shard_wait_piece(s, c, stream)
+ * orders `stream` behind that staging -- while columns c + 1 .. are still being factored: only the last piece's
+ * transfer is exposed.
  * world / rank need not be a process group's: a single process can play rank r of W (tools/emulate_rank.py).
  * Replaces the per-panel LAPACK dpotrf steps behind pt.slinalg.cholesky (gpmcmc.py:313) at a size one GPU need not hold. */
 typedef struct mi_gp_shard mi_gp_shard;
@@ -254,8 +266,8 @@ typedef struct {
   const double* y_dev;     /* n */
   double* K_dev;           /* (np + 128) x ldk, ldk >= owned panels * pw, even */
   long ldk;
-  double* P_dev[2];        /* panel buffers, (np + 256) x ldp each */
-  long ldp;
+  double* P_dev[2];        /* panel buffers, panel_tiles pieces of ldp doubles each */
+  long ldp;                /* piece stride, >= (np + 256) * 128 */
   const double* theta_dev; /* C-ABI theta on the device (the caller uploads it before begin) */
   int* info_dev;           /* [1] bad-pivot word: reset by begin, atomicMin(global column + 1) */
   double* out_dev;         /* [4] scalars of finish */
@@ -265,6 +277,8 @@ int mi_gp_shard_destroy(mi_gp_shard* s);
 int mi_gp_shard_begin(mi_gp_shard* s, int noise_form, void* main_stream, void* side_stream);
 int mi_gp_shard_step(mi_gp_shard* s, int j, void* main_stream, void* side_stream);
 int mi_gp_shard_finish(mi_gp_shard* s, void* main_stream, void* side_stream);
+/* `stream` waits until tile column c of the panel this rank factored last (begin: panel 0; step j: panel j + 1) is staged */
+int mi_gp_shard_wait_piece(mi_gp_shard* s, int c, void* hip_stream);
 /* options: 0 bulk updates at one workgroup per CU while this rank's side stream factors the next panel (default 1);
  *          1 record per-step HIP events (update / factor / stage on the side stream, bulk on the main stream);
  *          2 update the panel this rank factors in the NEXT step first and alone, so that its chain does not wait for the
@@ -275,6 +289,9 @@ int mi_gp_shard_finish(mi_gp_shard* s, void* main_stream, void* side_stream);
  *            ordered behind the staging when the call returns: the caller broadcasts the panel under side_stream.
  * what = 4: tiles of a bulk update that run one workgroup per CU beside this rank's own chain, the rest two per CU (2048;
  *            0: the whole update one per CU).
+ * what = 5: a chain on main_stream stages every tile column behind its strip (1), and the previous panel's update takes the
+ *            first tile column alone and first so that it is final, staged and sent early (2, the default); 0: the panel is
+ *            staged behind its last column.  0 and 1 give the same bits; 2 regroups launches (agreement to rounding).
  * Reproducibility: the sharded factorisation is bit-reproducible for a FIXED world size, panel width and option set.
  * Options 2 and 3 and the world size change which launches update a panel (the early next-panel update goes through the
  * ordinary launcher and may run on 64x64 tiles where the panel-list launch uses 128x128), i.e. they regroup sums: results
@@ -284,6 +301,9 @@ int mi_gp_shard_set_option(mi_gp_shard* s, int what, int value);
  * update_ms, factor_ms, stage_ms, bulk_ms of step j (0 where the step had no such phase; factor of panel 0 is in
  * out[4 * npanels + 1], its staging in out[4 * npanels + 2]); returns the number of steps written, < 0 on error */
 int mi_gp_shard_times(mi_gp_shard* s, double* out, int max_steps);
+/* out[j * panel_tiles + c] = ms from the start of step j's chain to the end of the staging of tile column c of the panel it
+ * produces (row npanels: panel 0, from the start of its factorisation); option 1; returns the number of steps written */
+int mi_gp_shard_piece_times(mi_gp_shard* s, double* out, int max_steps);
 /* 0: the chain runs on side_stream (it must then wait for panel j as well), 1: on main_stream (option 3) */
 int mi_gp_shard_chain_stream(const mi_gp_shard* s);
 const char* mi_gp_shard_last_error(mi_gp_shard* s);

@@ -125,6 +125,16 @@ for (N, d, kernel, pwt) in [(1500, 4, "RBF", None), (2100, 5, "Matern52", None),
     assert v4 == v3 and np.max(np.abs(g4 - g) / scale) <= 1e-9, (rank, N)
     gp.set_option(3, 1)
     assert gp.lml(theta) == val  # and back: bit-identical to the first evaluation
+    # the pipelined send: tile columns staged and broadcast one by one behind their strips (1) or the panel behind its last
+    # column (0) -- the same launches, the same bits; the default (2) also takes the first column's update first and alone
+    gp.set_option(5, 1)
+    v5 = gp.lml(theta)
+    gp.set_option(5, 0)
+    v6, g6 = gp.lml_grad(theta)
+    assert v5 == v6 and abs(v5 - val) <= 1e-11 * abs(val), (rank, N, v5, v6, val)
+    assert np.max(np.abs(g6 - g) / scale) <= 1e-9, (rank, N)
+    gp.set_option(5, 2)
+    assert gp.lml(theta) == val
 vals = parallel.gather_objects(out)
 assert all(v == vals[0] for v in vals), vals  # every rank holds the same all-reduced LML
 if rank == 0:
@@ -182,8 +192,13 @@ def test_emulated_ranks_partition_the_factorisation(world, pwt, N):
     for rank in range(world):
         gp = DistGP(X, y, "Matern52", panel_width_tiles=pwt, emulate=(world, rank))
         gp.set_factor_source(K, K.stride(0))
-        for early in (1, 0):  # option 2 only reorders launches of the same arithmetic per panel
+        # option 2 only reorders launches of the same arithmetic per panel; option 3 moves the owner's chain between the
+        # streams; option 5 stages (and sends) each tile column behind its strip (1), with the first column updated first and alone (2), or
+        # the panel behind its last column (0)
+        for early, on_main, piecewise in ((1, 1, 2), (0, 1, 2), (1, 1, 1), (1, 1, 0), (1, 0, 2), (0, 0, 2)):
             gp.set_option(2, early)
+            gp.set_option(3, on_main)
+            gp.set_option(5, piecewise)
             gp.lml(theta)
             torch.cuda.synchronize()
             for li, j in enumerate(gp.own):

@@ -4,6 +4,10 @@
   python tools/fullsize_parity.py c3grad   Matern-5/2 N=16384 d=16: LML + gradient vs oracle.lml_grad             (gpmcmc.py:345,351)
   python tools/fullsize_parity.py predict  Matern-5/2 N=16384 d=16, M=1000: posterior mean / variance through
                                            mi_gp_predict (blocked solve) and mi_gp_predict_u (K* U) vs oracle.predict (gpmcmc.py:588-598)
+  python tools/fullsize_parity.py c4grad   RBF N=65536 d=32: LML + gradient on ONE GPU through the single-GPU path (K, U, K^-1: 3 x 34 GB)
+                                           and through the sharded driver on one rank (gloo group of one), against each other and
+                                           against central differences of the device LML for four hyper-parameters (the CPU
+                                           restatement of the gradient at this size is ~1 h of host time: not run)
   options: --n N (smaller c4 when host RAM is short), --out FILE
 
 The oracle legs are NumPy / SciPy on the box's host cores: c4 assembles K row block by row block with the oracle's own
@@ -85,6 +89,50 @@ def main():
                "rel_diff_lml": abs(v - ref) / abs(ref), "grad_max_abs_diff_over_largest_component": float(np.abs(g - gref).max() / scale),
                "grad_max_rel_diff_per_component": float(np.max(np.abs(g - gref) / np.maximum(np.abs(gref), 1e-3 * scale))),
                "device_grad": g.tolist(), "oracle_grad": gref.tolist(), "device_ms": t_dev * 1e3, "oracle_s": t_cpu}
+    elif what == "c4grad":
+        import torch
+        N = int(sys.argv[sys.argv.index("--n") + 1]) if "--n" in sys.argv else 65536
+        d = 32
+        X, y = synth_problem(N, d, seed=0)
+        theta = np.concatenate([np.exp(np.linspace(np.log(0.8), np.log(3.0), d)), [1.7], [1.0], [1e-4, 1e-6]])
+        gp = MiGP(X, y, "RBF")
+        gp.lml_grad(theta)
+        t0 = time.perf_counter()
+        v, g = gp.lml_grad(theta)
+        t_one = time.perf_counter() - t0
+        print(f"single-GPU path: lml {v!r}, LML + gradient in {t_one:.2f} s", flush=True)
+        # central differences of the device LML (parity 2.5e-14 at this size, leg c4) for a few components
+        fd = {}
+        for k in (0, d - 1, d, d + 2):  # first / last length scale, kv, gv  (theta = [l(d), kv, RatQuad alpha slot, gv, jitter])
+            h = 1e-4 * theta[k]
+            tp, tm = theta.copy(), theta.copy()
+            tp[k] += h
+            tm[k] -= h
+            fd[k] = (gp.lml(tp) - gp.lml(tm)) / (2 * h)
+            print(f"  theta[{k}]: analytic {g[k]!r} central difference {fd[k]!r}", flush=True)
+        gp.close()
+        del gp
+        torch.cuda.empty_cache()
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+        from andvaranaut_amd.distributed import DistGP
+        sg = DistGP(X, y, "RBF", device=0)
+        sg.lml_grad(theta)
+        t0 = time.perf_counter()
+        v2, g2 = sg.lml_grad(theta)
+        t_sh = time.perf_counter() - t0
+        sg.close()
+        dist.destroy_process_group()
+        scale = np.abs(g).max()
+        rec = {"leg": "config 4 size: RBF LML + gradient", "N": N, "d": d, "lml_single_gpu_path": v, "lml_sharded_one_rank": v2,
+               "rel_diff_lml": abs(v - v2) / abs(v), "single_gpu_path_s": t_one, "sharded_one_rank_s": t_sh,
+               "grad_single_gpu_path": g.tolist(), "grad_sharded_one_rank": g2.tolist(),
+               "grad_max_abs_diff_over_largest_component": float(np.abs(g - g2).max() / scale),
+               "central_difference_check": {str(k): {"analytic": float(g[k]), "central_difference": float(fd[k]),
+                                                     "rel_diff": float(abs(g[k] - fd[k]) / max(abs(g[k]), 1e-3 * scale))} for k in fd},
+               "note": "central differences with h = 1e-4 theta_k of a value known to 2.5e-14: good to ~1e-6 of the largest component"}
     elif what == "predict":
         N, d, M = 16384, 16, 1000
         X, y = synth_problem(N, d, seed=0)

@@ -243,3 +243,49 @@ def test_kept_factor_of_the_sharded_gradient_equals_the_single_gpu_factor(chain_
         assert abs(val - v1) <= 1e-11 * abs(v1)
         assert _grad_close(g, g1, rtol=1e-8), (g, g1)
     one.close()
+
+
+RCCL_WORKER = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from andvaranaut_amd import MiGP
+from andvaranaut_amd.distributed import DistGP
+from oracle import gp_oracle as orc
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+N, d = 5000, 6
+X, y = orc.synth_problem(N, d, seed=3)
+theta = orc.synth_theta(d)
+one = MiGP(X, y, "Matern52")
+ref, gref = one.lml_grad(theta)
+one.close()
+gp = DistGP(X, y, "Matern52", device=0, panel_width_tiles=4)
+vals = {}
+for on_main, piecewise in ((0, 2), (1, 2), (1, 1), (1, 0)):
+    gp.set_option(3, on_main)
+    gp.set_option(5, piecewise)
+    v = gp.lml(theta)
+    v2, g = gp.lml_grad(theta)
+    assert v == v2 and abs(v - ref) <= 1e-11 * abs(ref), (on_main, piecewise, v, ref)
+    assert np.max(np.abs(g - gref)) <= 1e-9 * np.max(np.abs(gref)), (on_main, piecewise)
+    vals[(on_main, piecewise)] = v
+assert vals[(1, 1)] == vals[(1, 0)]  # the same launches, staged piece by piece or at the end
+assert gp.bytes_broadcast > 0
+dist.destroy_process_group()
+print(json.dumps({"ok": True}))
+'''
+
+
+def test_pipelined_exchange_over_a_one_rank_rccl_group(tmp_path):
+    """The exchange code path of a multi-GPU run -- one RCCL broadcast per tile column behind mi_gp_shard_wait_piece, sends
+    that the owner waits for only before it re-uses their buffer -- through the real backend ("nccl" = RCCL), as far as one
+    GPU allows: a group of one rank, with the owner's chain on the main stream (the several-rank default) and every
+    staging mode, against the single-GPU path."""
+    script = tmp_path / "worker.py"
+    script.write_text(RCCL_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert '"ok": true' in p.stdout

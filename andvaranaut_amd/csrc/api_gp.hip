@@ -11,6 +11,8 @@
 
 using namespace migp;
 
+constexpr int SIG_SLOTS = 1024;  // cross-stream edges of one evaluation (a 16384-point factorisation has ~60)
+
 struct mi_gp_handle {
   mi_gp_config cfg;
   KernSpec spec;
@@ -23,6 +25,16 @@ struct mi_gp_handle {
   size_t ev_next;                   // evaluation: a captured DAG then holds one node pair per hand-off)
   hipEvent_t wait_ev;               // recorded on the main stream behind the (a2) update of tile columns wait_col + 1 ..:
   int wait_col;                     // the panel stream waits for it after the leaf + strip of tile column wait_col
+  // Cross-stream edges as stream memory operations (round 4, option 26): `from` writes the evaluation's epoch into a slot of
+  // sig_dev behind its work (hipStreamWriteValue32), `to` waits for slot >= epoch (hipStreamWaitValue32).  Measured on
+  // MI355X (ping-pong of short kernels over two streams): +4-5 us per edge against +11-12 us with hipEventRecord +
+  // hipStreamWaitEvent.  One slot per edge of an evaluation, never re-used inside it; the epoch grows by one per
+  // factorisation, so a slot's old value never satisfies a new wait.
+  unsigned* sig_dev;                // [SIG_SLOTS]
+  unsigned sig_epoch;
+  int sig_next;
+  int wait_slot;                    // the slot that stands in for wait_ev
+  int use_smo;                      // option 26 (default 1; 0: events)
   // tuning options (mi_gp_set_option), all per handle
   int tail_small;   // option 9: 128x128-tile launches finish their last partial round on 64x64 tiles (default 1)
   int chain_prio;   // s_setprio(3) in the GEMM launches of the panel stream (option 16; the leaf and strip kernels always raise it)
@@ -98,7 +110,7 @@ static void release_handle(mi_gp_handle* h) {
   (void)hipSetDevice(h->device);
   if (h->pstream) (void)hipStreamSynchronize(h->pstream);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  (void)hipFree(h->theta_dev); (void)hipFree(h->dinv_dev); (void)hipFree(h->info_dev);
+  (void)hipFree(h->theta_dev); (void)hipFree(h->dinv_dev); (void)hipFree(h->info_dev); (void)hipFree(h->sig_dev);
   (void)hipFree(h->alpha_dev); (void)hipFree(h->part_dev); (void)hipFree(h->gxs_dev);
   (void)hipFree(h->lr_part_dev); (void)hipFree(h->lr_sync_dev); (void)hipFree(h->b_lr_part_dev); (void)hipFree(h->b_lr_sync_dev);
   (void)hipFree(h->b_theta_dev); (void)hipFree(h->b_dinv_dev); (void)hipFree(h->b_alpha_dev); (void)hipFree(h->b_part_dev);
@@ -166,9 +178,13 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   h->split_tiles = 2048;
   h->split_min_rest = 1024;
   h->merge_min_tiles = 72;
-  h->single_below = 16;
+  h->single_below = 8;  // (16 with event hand-offs; with option 26: N = 4096 1.983 -> 1.958 ms, 8192 5.50 -> 5.49, 16384 26.84 -> 26.73)
   h->asm_split = 1;
   h->asm_ev_valid = false;
+  h->use_smo = 1;
+  h->sig_epoch = 0;
+  h->sig_next = 0;
+  h->wait_slot = -1;
   // round-2 A/B (tools/dev_ab_opts.py, interleaved in one process): bulk updates at one workgroup per CU whenever the
   // panel chain runs beside them (N = 16384: 29.99 -> 28.97 ms) and 8-tile super-panels at every size (N = 2048 1.045 ->
   // 1.017 ms, 4096 2.470 -> 2.388, 8192 6.417 -> 6.348, 16384 28.59 -> 28.39 against the 8 / 4 split of round 1)
@@ -180,6 +196,8 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   if (e == hipSuccess) e = hipMalloc(&h->part_dev, sizeof(double) * (size_t)grad_contract_blocks(h->n) * h->ntheta);
   if (e == hipSuccess) e = hipHostMalloc(&h->grad_host, sizeof(double) * h->ntheta);
   if (e == hipSuccess) e = hipMalloc(&h->info_dev, sizeof(int) * 4);
+  if (e == hipSuccess) e = hipMalloc(&h->sig_dev, sizeof(unsigned) * SIG_SLOTS);
+  if (e == hipSuccess) e = hipMemset(h->sig_dev, 0, sizeof(unsigned) * SIG_SLOTS);
   if (e == hipSuccess) e = hipMalloc(&h->lr_part_dev, sizeof(double) * 2 * LML_REDUCE_BLOCKS);
   if (e == hipSuccess) e = hipMalloc(&h->lr_sync_dev, sizeof(unsigned));
   if (e == hipSuccess) e = hipMemset(h->lr_sync_dev, 0, sizeof(unsigned));
@@ -237,6 +255,7 @@ extern "C" int mi_gp_set_option(mi_gp_handle* h, int what, int value) {
   else if (what == 20) h->merge_min_tiles = value;
   else if (what == 21) h->single_below = value;
   else if (what == 24) h->asm_split = value ? 1 : 0;
+  else if (what == 26) h->use_smo = value ? 1 : 0;
   else if (what == 9) h->tail_small = value ? 1 : 0;
   else {
     snprintf(h->err, sizeof(h->err), "mi_gp_set_option: unknown option %d", what);
@@ -334,7 +353,8 @@ static hipError_t chol_panel(mi_gp_handle* h, double* A, long lda, int ntr, int 
     if (e == hipSuccess && m > 128) e = launch_trsm_strip128(dinv, blk + 128 * lda, lda, m, st, h->btp, h->btp ? h->btp->sK : 0);
     if (e == hipSuccess && c0 == h->wait_col) {  // the super-panel's other columns are being updated on the main stream
       h->wait_col = -1;
-      e = hipStreamWaitEvent(st, h->wait_ev, 0);
+      e = h->wait_slot >= 0 ? hipStreamWaitValue32(st, h->sig_dev + h->wait_slot, h->sig_epoch, hipStreamWaitValueGte, 0xffffffffu)
+                            : hipStreamWaitEvent(st, h->wait_ev, 0);
     }
     return e;
   }
@@ -378,8 +398,20 @@ static hipError_t next_event(mi_gp_handle* h, hipEvent_t* out) {
   return hipSuccess;
 }
 
+// a fresh signal slot of this evaluation, written behind everything queued on `from` so far; -1: none left / events in use
+static int signal_from(mi_gp_handle* h, hipStream_t from, hipError_t* e) {
+  *e = hipSuccess;
+  if (!h->use_smo || h->sig_next >= SIG_SLOTS) return -1;
+  const int slot = h->sig_next++;
+  *e = hipStreamWriteValue32(from, h->sig_dev + slot, h->sig_epoch, 0);
+  return slot;
+}
+
 // `to` waits for everything queued on `from` so far
 static hipError_t hand_off(mi_gp_handle* h, hipStream_t from, hipStream_t to) {
+  hipError_t se;
+  const int slot = signal_from(h, from, &se);
+  if (slot >= 0) return se != hipSuccess ? se : hipStreamWaitValue32(to, h->sig_dev + slot, h->sig_epoch, hipStreamWaitValueGte, 0xffffffffu);
   hipEvent_t ev;
   hipError_t e = next_event(h, &ev);
   if (e != hipSuccess) return e;
@@ -391,8 +423,11 @@ static hipError_t hand_off(mi_gp_handle* h, hipStream_t from, hipStream_t to) {
 // Below this many tile columns one stream is faster than two: the cross-stream hand-offs cost more than the overlap
 // returns (one stream vs two, end of round 2: N = 2048 0.94 vs 1.01 ms, N = 4096 2.235 vs 2.252, N = 4608 2.513 vs 2.472,
 // N = 5120 2.849 vs 2.820, N = 6144 3.81 vs 3.59, N = 8192 6.35 vs 5.67).
-constexpr int LOOKAHEAD_MIN_TILES = 28;  // round 4: with the single-stream tail (option 21) two streams win from 28 tile columns on
-                                       // (N = 3584 1.735 -> 1.670 ms, 4096 2.099 -> 2.054; N = 3072 1.372 vs 1.397: one stream stays)
+constexpr int LOOKAHEAD_MIN_TILES = 20;  // round 4: with the single-stream tail (option 21) two streams won from 28 tile columns on
+                                       // (N = 3584 1.735 -> 1.670 ms, 4096 2.099 -> 2.054); with the hand-offs as stream memory
+                                       // operations (option 26) from 20 (one stream vs two: N = 2048 0.875 vs 0.908 ms, 2304 1.026 vs
+                                       // 1.022, 2560 1.145 vs 1.119, 2816 1.268 vs 1.251, 3072 1.373 vs 1.352, 3328 1.532 vs 1.484,
+                                       // 3584 1.736 vs 1.606)
 
 static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int ntc) {
   // A batched evaluation (blockIdx.z = problem) carries nb times the work per launch, so the look-ahead pays from smaller
@@ -406,6 +441,14 @@ static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int nt
 #define CKE(x) do { e = (x); if (e != hipSuccess) return e; } while (0)
   h->ev_next = 0;
   h->wait_col = -1;
+  h->sig_next = 0;
+  h->wait_slot = -1;
+  if (++h->sig_epoch == 0xffffffffu) {  // (4e9 factorisations on one handle: start over)
+    CKE(hipStreamSynchronize(h->stream));
+    CKE(hipStreamSynchronize(h->pstream));
+    CKE(hipMemset(h->sig_dev, 0, sizeof(unsigned) * SIG_SLOTS));
+    h->sig_epoch = 1;
+  }
   // the panel stream starts after what is queued on the main stream (assembly) -- or, when the assembly was split, after its
   // first part (the first super-panel's columns); the first main-stream update sits behind the second part anyway
   if (P != T) {
@@ -467,8 +510,12 @@ static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int nt
       CKE(syrk_trapezoid(h, A, lda, ntr, n1, 1, J, w, P));
       if (wn > 1) {
         CKE(syrk_trapezoid(h, A, lda, ntr, n1 + 1, wn - 1, J, w, T));
-        CKE(next_event(h, &h->wait_ev));
-        CKE(hipEventRecord(h->wait_ev, T));
+        h->wait_slot = signal_from(h, T, &e);
+        if (e != hipSuccess) return e;
+        if (h->wait_slot < 0) {
+          CKE(next_event(h, &h->wait_ev));
+          CKE(hipEventRecord(h->wait_ev, T));
+        }
         h->wait_col = n1;
       }
     } else {

@@ -500,13 +500,13 @@ class GPMCMC(ConsumersMixin):
         def run_lane(dev, cs, h_existing, shared):
             try:
                 h = h_existing or MiGP(xin, yin, self.kernel, device=dev)
-                # Lanes that SHARE a GPU give up the look-ahead stream between 28 and 64 tile columns: the other lanes fill
+                # Lanes that SHARE a GPU give up the look-ahead stream between 20 and 64 tile columns: the other lanes fill
                 # the idle CUs anyway and a hand-off between two streams costs ~10 us (three handles, LML + gradient: N = 6144
                 # 176 -> 202 evaluations/s, N = 8192 94 -> 97; from 72 tile columns on there is nothing in it).  The
                 # super-panel width is pinned to the one the two-stream driver would pick, so the arithmetic -- and every
                 # draw -- is bit-identical to the default schedule.
                 ntc = (len(yin) + 127) // 128
-                pinned = shared and 28 <= ntc <= 64
+                pinned = shared and 20 <= ntc <= 64
                 if pinned:
                     # the caller's own handle gets its previous settings back afterwards (library defaults: look-ahead by
                     # size = 1, super-panel width by size = 0)

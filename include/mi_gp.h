@@ -148,11 +148,14 @@ int mi_gp_predict_grad(mi_gp_handle* h, const double* Xnew_dev, int m, double* w
  *   19 ... only when at least this many tiles remain for the second part (default 1024)
  *   20 trailing tile columns from which the next super-panel's update rides at the head of the trailing update's tile
  *      enumeration instead of in launches of its own (default 72, 0: never)
- *   21 trailing tile columns at or below which a two-stream factorisation continues on the main stream alone (default 16)
+ *   21 trailing tile columns at or below which a two-stream factorisation continues on the main stream alone (default 8)
  *   24 large two-stream evaluations assemble the first super-panel's columns first and the rest of K beside its
  *      factorisation, one workgroup per CU (default 1)
- * 8, 14, 16, 18, 19, 21 and 24 only change scheduling (bit-identical results); 20 moves tiles between the two GEMM kernels (same k order); 2, 4-7, 9 regroup sums (agreement to rounding), and so does 0 where
- * it changes the super-panel width (36 to 64 tile columns).
+ *   26 cross-stream edges of the factorisation as stream memory operations -- hipStreamWriteValue32 behind the producer's
+ *      work, hipStreamWaitValue32 in front of the consumer's -- instead of hipEventRecord + hipStreamWaitEvent (default 1:
+ *      4-5 us per edge instead of 11-12 on MI355X; N = 6144 3.40 -> 3.26 ms)
+ * 8, 14, 16, 18, 19, 21, 24 and 26 only change scheduling (bit-identical results); 20 moves tiles between the two GEMM kernels (same k order); 2, 4-7, 9 regroup sums (agreement to rounding), and so does 0 where
+ * it changes the super-panel width (20 to 64 tile columns).
  * Unknown ids return -1.  (Round 1's options 1, 3, 10-13 -- GEMM variants, hipGraph replay, persistent bulk kernels,
  * exclusive leaf, fused leaf + strip -- are gone with the code they selected.) */
 int mi_gp_set_option(mi_gp_handle* h, int what, int value);

@@ -90,7 +90,7 @@ def test_ragged_large_size_through_the_split_and_merged_launches():
     """The round-4 driver paths that only large problems reach (api_gp.hip cholesky(): merged head from 72 trailing tile
     columns, split bulk update, single-stream tail) at a size that is NOT a multiple of anything: N = 10300 (81 tile columns,
     ragged last super-panel).  LML against the oracle at the north star's 1e-10, and the scheduling-only options
-    (include/mi_gp.h: 18, 19, 21 bit-identical; 20 same k order per tile) must not change a bit.  gpmcmc.py:313."""
+    (include/mi_gp.h: 18, 19, 21, 24, 26 bit-identical; 20 same k order per tile) must not change a bit.  gpmcmc.py:313."""
     from andvaranaut_amd import MiGP
     from bench import reference_theta, synth_problem
     from oracle import gp_oracle as orc
@@ -102,10 +102,10 @@ def test_ragged_large_size_through_the_split_and_merged_launches():
     gp = MiGP(X, y, "Matern52", need_grad=False)
     v0 = gp.lml(theta)
     assert abs(v0 - ref) <= 1e-10 * abs(ref), (v0, ref)
-    for opts in ({18: 0}, {20: 0}, {21: 0}, {18: 0, 20: 0, 21: 0}, {18: 1024, 19: 256, 20: 40}):
+    for opts in ({18: 0}, {20: 0}, {21: 0}, {18: 0, 20: 0, 21: 0}, {18: 1024, 19: 256, 20: 40}, {26: 0}, {26: 0, 21: 16, 24: 0}):
         for k, v in opts.items():
             gp.set_option(k, v)
         assert gp.lml(theta) == v0, opts
-        for k, v in {18: 2048, 19: 1024, 20: 72, 21: 16}.items():
+        for k, v in {18: 2048, 19: 1024, 20: 72, 21: 8, 24: 1, 26: 1}.items():
             gp.set_option(k, v)
     gp.close()

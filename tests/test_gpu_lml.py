@@ -251,7 +251,7 @@ def test_tuning_options_do_not_change_results():
 
 
 def test_shared_lane_schedule_is_bit_identical_to_the_default():
-    """GPMCMC.fit runs chains that share a GPU on single-stream handles between 28 and 64 tile columns, with the
+    """GPMCMC.fit runs chains that share a GPU on single-stream handles between 20 and 64 tile columns, with the
     super-panel width the two-stream default would pick pinned (options 2 = 4, 0 = 0): same arithmetic, same bits --
     every draw of a chain equals the default schedule's."""
     MiGP, orc = _mods()

@@ -680,18 +680,15 @@ __device__ __forceinline__ void trsm_strip128_body(const double* __restrict__ mi
   const int n = lane & 15, q = lane >> 4;
   const int jb0 = wave, jb1 = 7 - wave;  // jb0 < jb1; k-blocks 0 .. jb1 are needed
   double* Brow = B + ((long)blk * (16 * RG) + n) * ldb + 4 * q;
-  double2_t a[2][8][2];  // two row groups in flight
-  auto load_rows = [&](int set, int rg) {
+  double2_t a[8][2];  // ONE row group's operands; a k-block's pair is refilled with the next group's as soon as it is consumed
+  auto load_kb = [&](int rg, int kb) {
     const double* src = Brow + (long)rg * 16 * ldb;
-#pragma unroll
-    for (int kb = 0; kb < 8; ++kb) {
-      if (kb <= jb1) {
-        a[set][kb][0] = *reinterpret_cast<const double2_t*>(src + 16 * kb);
-        a[set][kb][1] = *reinterpret_cast<const double2_t*>(src + 16 * kb + 2);
-      }
-    }
+    a[kb][0] = *reinterpret_cast<const double2_t*>(src + 16 * kb);
+    a[kb][1] = *reinterpret_cast<const double2_t*>(src + 16 * kb + 2);
   };
-  load_rows(0, 0);
+#pragma unroll
+  for (int kb = 0; kb < 8; ++kb)
+    if (kb <= jb1) load_kb(0, kb);
   // M rows 16 jb + n, k-blocks 0 .. jb: (jb0 + 1) + (jb1 + 1) = 9 fetches of 4 doubles per lane
   const double* m0 = minv + (long)(16 * jb0 + n) * LEAF + 4 * q;
   const double* m1 = minv + (long)(16 * jb1 + n) * LEAF + 4 * q;
@@ -712,24 +709,31 @@ __device__ __forceinline__ void trsm_strip128_body(const double* __restrict__ mi
   }
 #pragma unroll
   for (int rg = 0; rg < RG; ++rg) {
-    const int cur = rg & 1;
-    if (rg + 1 < RG) load_rows(cur ^ 1, rg + 1);
-    double4_t x0 = {0.0, 0.0, 0.0, 0.0}, x1 = {0.0, 0.0, 0.0, 0.0};
+    // Four partial accumulators per output tile, one per MFMA step of a k-block (round 4): a dependent fp64 MFMA follows
+    // its predecessor after ~250 cycles but an independent one after 64, and with ONE accumulator per tile the wave that
+    // owns column block 7 ran a chain of 32 per row group (8000 of the ~16000 cycles of a one-group strip, and nearly all
+    // of a four-group strip's 16 us).  Now the longest chain is 8 deep and the partial sums are added pairwise at the end.
+    // The registers for the partials come from the second operand set of rounds 2-3 (two row groups in flight): a k-block's
+    // operands are refilled with the next group's right behind their last MFMA instead, still a whole MFMA phase ahead.
+    const double4_t zero4 = {0.0, 0.0, 0.0, 0.0};
+    double4_t p1[4] = {zero4, zero4, zero4, zero4}, p0[4] = {zero4, zero4, zero4, zero4};
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb) {
       if (kb <= jb1) {
-        x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur][kb][0].x, b1[kb][0].x, x1, 0, 0, 0);
-        x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur][kb][0].y, b1[kb][0].y, x1, 0, 0, 0);
-        x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur][kb][1].x, b1[kb][1].x, x1, 0, 0, 0);
-        x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur][kb][1].y, b1[kb][1].y, x1, 0, 0, 0);
+        p1[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kb][0].x, b1[kb][0].x, p1[0], 0, 0, 0);
+        p1[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kb][0].y, b1[kb][0].y, p1[1], 0, 0, 0);
+        p1[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kb][1].x, b1[kb][1].x, p1[2], 0, 0, 0);
+        p1[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kb][1].y, b1[kb][1].y, p1[3], 0, 0, 0);
       }
       if (kb < 4 && kb <= jb0) {
-        x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur][kb][0].x, b0[kb][0].x, x0, 0, 0, 0);
-        x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur][kb][0].y, b0[kb][0].y, x0, 0, 0, 0);
-        x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur][kb][1].x, b0[kb][1].x, x0, 0, 0, 0);
-        x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur][kb][1].y, b0[kb][1].y, x0, 0, 0, 0);
+        p0[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kb][0].x, b0[kb][0].x, p0[0], 0, 0, 0);
+        p0[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kb][0].y, b0[kb][0].y, p0[1], 0, 0, 0);
+        p0[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kb][1].x, b0[kb][1].x, p0[2], 0, 0, 0);
+        p0[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kb][1].y, b0[kb][1].y, p0[3], 0, 0, 0);
       }
+      if (rg + 1 < RG && kb <= jb1) load_kb(rg + 1, kb);
     }
+    const double4_t x0 = (p0[0] + p0[1]) + (p0[2] + p0[3]), x1 = (p1[0] + p1[1]) + (p1[2] + p1[3]);
     // every wave's copy of this row group is in registers (its MFMAs consumed it; the next group's loads may still be
     // in flight, they touch other rows) before anybody overwrites the group
     if (rg + 1 < RG) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(16) : "memory");

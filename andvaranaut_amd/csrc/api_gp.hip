@@ -34,7 +34,8 @@ struct mi_gp_handle {
   unsigned sig_epoch;
   int sig_next;
   int wait_slot;                    // the slot that stands in for wait_ev
-  int use_smo;                      // option 26 (default 1; 0: events)
+  int use_smo;                      // option 26: 0 events, 1 runtime stream memory operations, 2 (default) the panel stream's
+                                    // halves folded into one-lane launches of the library / the end of a leaf
   // tuning options (mi_gp_set_option), all per handle
   int tail_small;   // option 9: 128x128-tile launches finish their last partial round on 64x64 tiles (default 1)
   int chain_prio;   // s_setprio(3) in the GEMM launches of the panel stream (option 16; the leaf and strip kernels always raise it)
@@ -181,7 +182,7 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   h->single_below = 8;  // (16 with event hand-offs; with option 26: N = 4096 1.983 -> 1.958 ms, 8192 5.50 -> 5.49, 16384 26.84 -> 26.73)
   h->asm_split = 1;
   h->asm_ev_valid = false;
-  h->use_smo = 1;
+  h->use_smo = 2;
   h->sig_epoch = 0;
   h->sig_next = 0;
   h->wait_slot = -1;
@@ -255,7 +256,7 @@ extern "C" int mi_gp_set_option(mi_gp_handle* h, int what, int value) {
   else if (what == 20) h->merge_min_tiles = value;
   else if (what == 21) h->single_below = value;
   else if (what == 24) h->asm_split = value ? 1 : 0;
-  else if (what == 26) h->use_smo = value ? 1 : 0;
+  else if (what == 26) h->use_smo = value < 0 ? 0 : value > 2 ? 2 : value;
   else if (what == 9) h->tail_small = value ? 1 : 0;
   else {
     snprintf(h->err, sizeof(h->err), "mi_gp_set_option: unknown option %d", what);
@@ -349,12 +350,19 @@ static hipError_t chol_panel(mi_gp_handle* h, double* A, long lda, int ntr, int 
     const int m = (ntr - c0 - 1) * 128;
     // (the trapezoid's last tile row is the y^T block: below the last tile column there is nothing else, and the leaf
     // solves that one row itself)
-    e = launch_potrf_leaf128(blk, lda, dinv, c0 * 128, h->info_dev, st, m == 128 ? blk + 128 * lda : nullptr, h->btp);
+    // the super-panel's other columns are being updated on the main stream ((a2)); their first reader is the in-panel update
+    // behind this column's strip.  Option 26 = 2: this leaf polls for that update's signal before it ends (it is done by
+    // then as a rule: it started with (a1)); otherwise a runtime wait behind the strip.
+    const bool waits = c0 == h->wait_col;
+    const bool folded = waits && h->wait_slot >= 0 && h->use_smo >= 2;
+    e = launch_potrf_leaf128(blk, lda, dinv, c0 * 128, h->info_dev, st, m == 128 ? blk + 128 * lda : nullptr, h->btp,
+                             folded ? h->sig_dev + h->wait_slot : nullptr, h->sig_epoch);
     if (e == hipSuccess && m > 128) e = launch_trsm_strip128(dinv, blk + 128 * lda, lda, m, st, h->btp, h->btp ? h->btp->sK : 0);
-    if (e == hipSuccess && c0 == h->wait_col) {  // the super-panel's other columns are being updated on the main stream
+    if (e == hipSuccess && waits) {
       h->wait_col = -1;
-      e = h->wait_slot >= 0 ? hipStreamWaitValue32(st, h->sig_dev + h->wait_slot, h->sig_epoch, hipStreamWaitValueGte, 0xffffffffu)
-                            : hipStreamWaitEvent(st, h->wait_ev, 0);
+      if (!folded)
+        e = h->wait_slot >= 0 ? hipStreamWaitValue32(st, h->sig_dev + h->wait_slot, h->sig_epoch, hipStreamWaitValueGte, 0xffffffffu)
+                              : hipStreamWaitEvent(st, h->wait_ev, 0);
     }
     return e;
   }
@@ -461,7 +469,29 @@ static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int nt
   CKE(chol_panel(h, A, lda, ntr, 0, w, P));
   for (int J = 0; J < ntc;) {
     const int n1 = J + w;  // first tile column right of this super-panel
-    if (P != T) CKE(hand_off(h, P, T));  // the main stream may read super-panel J from here on
+    // The panel stream's edges at a super-panel boundary: it tells the main stream that super-panel J is done (the main
+    // stream may read it from here on) and, when it goes on to the next panel on its own stream, it waits for the main
+    // stream's previous update of that panel's first column (the T -> P edge further down).  With option 26 = 2 the two are
+    // ONE one-lane launch on the panel stream (write, then poll) instead of two runtime kernels; the main stream's halves
+    // stay runtime stream memory operations.
+    int tp_slot = -1;  // >= 0: the panel stream already waits for this slot; the T -> P edge below only has to write it
+    if (P != T) {
+      const bool stays_two = n1 < ntc && !(ntc - n1 <= h->single_below / nb);
+      bool tp_edge = false;
+      if (stays_two) {
+        const int wn_ = pick_w(h, ntc - n1, wcap);
+        const bool merged_ = n1 + wn_ < ntc && h->merge_min_tiles > 0 && ntc - n1 >= h->merge_min_tiles;
+        tp_edge = merged_ || J > 0;
+      }
+      if (h->use_smo >= 2 && tp_edge && h->sig_next + 2 <= SIG_SLOTS) {
+        const int a = h->sig_next++;
+        tp_slot = h->sig_next++;
+        CKE(launch_signal_write_wait(h->sig_dev + a, h->sig_dev + tp_slot, h->sig_epoch, h->info_dev, P));
+        CKE(hipStreamWaitValue32(T, h->sig_dev + a, h->sig_epoch, hipStreamWaitValueGte, 0xffffffffu));
+      } else {
+        CKE(hand_off(h, P, T));
+      }
+    }
     if (n1 >= ntc) break;
     // The END of a large factorisation is a small one: below LOOKAHEAD_MIN_TILES trailing columns the cross-stream hand-offs
     // cost more than the overlap returns (that is why small problems run on one stream), so the rest runs on the main
@@ -486,7 +516,8 @@ static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int nt
       int x1 = (ft + 511) / 512 * 512;
       if (x1 > atiles) x1 = atiles;
       CKE(syrk_trapezoid(h, A, lda, ntr, n1, ac, J, w, T, 0, 0, x1, wn));
-      CKE(hand_off(h, T, P));
+      if (tp_slot >= 0) CKE(hipStreamWriteValue32(T, h->sig_dev + tp_slot, h->sig_epoch, 0));
+      else CKE(hand_off(h, T, P));
       int done = x1;
       if (low && h->split_tiles > 0 && atiles - done >= h->split_tiles + h->split_min_rest) {
         CKE(syrk_trapezoid(h, A, lda, ntr, n1, ac, J, w, T, 1, done, h->split_tiles, wn));
@@ -506,7 +537,10 @@ static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int nt
       //      the critical path per super-panel).  That column was last touched by the previous step's bulk update (b)
       //      on the main stream: wait for it first.
       // (a2) the other columns on the main stream meanwhile; the panel stream waits for them after that leaf + strip
-      if (J > 0) CKE(hand_off(h, T, P));
+      if (J > 0) {
+        if (tp_slot >= 0) CKE(hipStreamWriteValue32(T, h->sig_dev + tp_slot, h->sig_epoch, 0));
+        else CKE(hand_off(h, T, P));
+      }
       CKE(syrk_trapezoid(h, A, lda, ntr, n1, 1, J, w, P));
       if (wn > 1) {
         CKE(syrk_trapezoid(h, A, lda, ntr, n1 + 1, wn - 1, J, w, T));
@@ -646,6 +680,10 @@ static int factor_internal(mi_gp_handle* h, const double* theta, int what) {
     }
   }
   const int info = (int)h->out_host[3];  // forwarded by lml_reduce_kernel (reset by set_yrows_kernel)
+  if (info == SIGNAL_TIMEOUT_INFO) {
+    snprintf(h->err, sizeof(h->err), "a cross-stream signal of the factorisation was not seen within its poll limit");
+    return -2;
+  }
   if (info != 0x7f7f7f7f) return info;  // 1-based index of the first bad pivot
   return 0;
 }

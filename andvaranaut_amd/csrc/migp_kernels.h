@@ -84,8 +84,13 @@ constexpr int MINV_ELEMS = 128 * 128;  // doubles per leaf inverse
 // zeros above the diagonal inside the diagonal 16x16 tiles; the tiles above the block diagonal are not written and
 // never read); *info gets atomicMin(col0 + j + 1) on a bad pivot.
 // yrow (optional): row 0 of the 128-row block right below Ablk, solved in place against the leaf's inverse (beta = y M^T)
+// wait_ptr (optional): the launch ends only once *wait_ptr >= wait_val (a cross-stream signal; see leaf_f64.hip)
 hipError_t launch_potrf_leaf128(double* Ablk, long lda, double* minv, int col0, int* info, hipStream_t stream,
-                                double* yrow = nullptr, const Batch* bt = nullptr);
+                                double* yrow = nullptr, const Batch* bt = nullptr, const unsigned* wait_ptr = nullptr,
+                                unsigned wait_val = 0);
+// one lane: *wr = val (if wr), then wait for *wt >= val (if wt); a poll that gives up puts SIGNAL_TIMEOUT_INFO into *info
+constexpr int SIGNAL_TIMEOUT_INFO = -99;
+hipError_t launch_signal_write_wait(unsigned* wr, const unsigned* wt, unsigned val, int* info, hipStream_t stream);
 // X * L^T = B in place on the m x 128 panel B (m multiple of 16, ldb even) as X = B * M^T with the leaf's inverse M.
 hipError_t launch_trsm_strip128(const double* minv, double* B, long ldb, int m, hipStream_t stream, const Batch* bt = nullptr,
                                 long sB2 = 0);

@@ -151,9 +151,12 @@ int mi_gp_predict_grad(mi_gp_handle* h, const double* Xnew_dev, int m, double* w
  *   21 trailing tile columns at or below which a two-stream factorisation continues on the main stream alone (default 8)
  *   24 large two-stream evaluations assemble the first super-panel's columns first and the rest of K beside its
  *      factorisation, one workgroup per CU (default 1)
- *   26 cross-stream edges of the factorisation as stream memory operations -- hipStreamWriteValue32 behind the producer's
- *      work, hipStreamWaitValue32 in front of the consumer's -- instead of hipEventRecord + hipStreamWaitEvent (default 1:
- *      4-5 us per edge instead of 11-12 on MI355X; N = 6144 3.40 -> 3.26 ms)
+ *   26 cross-stream edges of the factorisation: 0 hipEventRecord + hipStreamWaitEvent; 1 stream memory operations --
+ *      hipStreamWriteValue32 behind the producer's work, hipStreamWaitValue32 in front of the consumer's (4-5 us per edge
+ *      instead of 11-12 on MI355X; N = 6144 3.40 -> 3.26 ms); 2 (default) the same protocol with the PANEL stream's halves
+ *      folded into launches of the library: its write + wait at a super-panel boundary is one one-lane launch, its wait
+ *      for the next-panel update is a poll at the end of the leaf in front of the first reader (N = 4096 1.995 -> 1.965 ms).
+ *      A poll that sees nothing for seconds gives up and the evaluation returns -2.
  * 8, 14, 16, 18, 19, 21, 24 and 26 only change scheduling (bit-identical results); 20 moves tiles between the two GEMM kernels (same k order); 2, 4-7, 9 regroup sums (agreement to rounding), and so does 0 where
  * it changes the super-panel width (20 to 64 tile columns).
  * Unknown ids return -1.  (Round 1's options 1, 3, 10-13 -- GEMM variants, hipGraph replay, persistent bulk kernels,

@@ -19,13 +19,18 @@ namespace {
 
 typedef double double2_t __attribute__((ext_vector_type(2)));
 
-// dst[r][c] = src[r][c], rows x cols doubles (cols even, both bases 16-byte aligned)
-__global__ void copy_panel_kernel(double* __restrict__ dst, long ldd, const double* __restrict__ src, long lds, int rows,
-                                  int cols2) {
-  const long total = (long)rows * cols2;
+// one piece of a panel buffer in ONE launch: rows x 128 doubles of a tile column (row stride lds) -> dst (row stride 128), then the
+// column's 128 x 128 leaf inverse behind them (a separate hipMemcpyAsync cost a second boundary on the owner's chain)
+__global__ void copy_piece_kernel(double* __restrict__ dst, const double* __restrict__ src, long lds, int rows,
+                                  const double* __restrict__ dinv) {
+  const long body = (long)rows * 64, total = body + MINV_ELEMS / 2;
   for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    const int r = (int)(e / cols2), c = (int)(e % cols2);
-    reinterpret_cast<double2_t*>(dst + (long)r * ldd)[c] = reinterpret_cast<const double2_t*>(src + (long)r * lds)[c];
+    if (e < body) {
+      const int r = (int)(e >> 6), c = (int)(e & 63);
+      reinterpret_cast<double2_t*>(dst + (long)r * 128)[c] = reinterpret_cast<const double2_t*>(src + (long)r * lds)[c];
+    } else {
+      reinterpret_cast<double2_t*>(dst + (long)rows * 128)[e - body] = reinterpret_cast<const double2_t*>(dinv)[e - body];
+    }
   }
 }
 
@@ -212,13 +217,10 @@ static hipError_t stage_piece(mi_gp_shard* s, int j, int li, int c, double* buf,
   const int r0 = j * s->pw, rows = s->np + 128 - r0;
   const double* src = s->cfg.K_dev + (long)r0 * s->cfg.ldk + (long)li * s->pw + (long)c * 128;
   double* dst = buf + (long)c * s->cfg.ldp;
-  const long total = (long)rows * 64;
+  const long total = (long)rows * 64 + MINV_ELEMS / 2;
   int blocks = (int)std::min<long>((total + 255) / 256, 4096);
-  copy_panel_kernel<<<blocks, 256, 0, st>>>(dst, 128, src, s->cfg.ldk, rows, 64);
+  copy_piece_kernel<<<blocks, 256, 0, st>>>(dst, src, s->cfg.ldk, rows, s->dinv_dev + (size_t)c * MINV_ELEMS);
   hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  e = hipMemcpyAsync(dst + (long)rows * 128, s->dinv_dev + (size_t)c * MINV_ELEMS, sizeof(double) * MINV_ELEMS,
-                     hipMemcpyDeviceToDevice, st);
   if (e != hipSuccess) return e;
   if (s->prof && s->prof_step >= 0) {
     const size_t need = (size_t)(s->npan + 1) * s->pwt;

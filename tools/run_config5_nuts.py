@@ -101,8 +101,11 @@ def main():
     ths = [threading.Thread(target=lane, args=(c,)) for c in range(args.chains)]
     for t in ths:
         t.start()
-    for t in ths:
-        t.join()
+    while any(t.is_alive() for t in ths):  # a line a minute: early tuning iterations can take minutes per hundred
+        for t in ths:
+            t.join(timeout=60.0 / len(ths))
+        if ev is not None and any(t.is_alive() for t in ths):
+            print(f"  t={time.perf_counter() - t0:7.0f} s: {ev.rounds} batched rounds, {ev.evaluations} evaluations", flush=True)
     dt = time.perf_counter() - t0
     if errs:
         raise SystemExit("a chain failed: " + "; ".join(errs))

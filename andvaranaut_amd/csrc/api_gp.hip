@@ -176,7 +176,8 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   h->chain_prio = 1;  // N = 8192: 6.06 -> 5.94 ms, N = 16384: 28.11 -> 27.74 ms (interleaved A/B)
   h->small_below = GemmParams().small_below;
   h->band_rows = GemmParams().band;
-  h->split_tiles = 2048;
+  h->split_tiles = 1536;  // (2048 until the chain got shorter -- stream memory operations, strip kernel: N = 16384 26.21 -> 25.96 ms,
+                          // 1024: 26.21, 1280: 26.09, 1792: 26.08; N = 12288 flat)
   h->split_min_rest = 1024;
   h->merge_min_tiles = 72;
   h->single_below = 8;  // (16 with event hand-offs; with option 26: N = 4096 1.983 -> 1.958 ms, 8192 5.50 -> 5.49, 16384 26.84 -> 26.73)
@@ -385,7 +386,8 @@ static hipError_t chol_panel(mi_gp_handle* h, double* A, long lda, int ntr, int 
 // of round 2: N = 4608 2.510 vs 2.475 ms, 5120 2.840 vs 2.725, 6144 3.602 vs 3.504, 7168 4.628 vs 4.538, 8192 5.742 vs
 // 5.678; 9216 equal, 10240 9.05 vs 9.14, 16384 27.4 vs 28.8 -- and 4-tile panels only for the last 52 / 64 columns of
 // larger problems lose 1-2 %).  An explicit panel_tiles (option 2) overrides everything.
-constexpr int NARROW_PANELS_MAX_TILES = 64;
+constexpr int NARROW_PANELS_MAX_TILES = 60;  // (64 until the end of round 4: with the cheaper cross-stream edges N = 8192 runs 5.41 vs 5.33 ms
+                                           // on 4- vs 8-tile panels; 7168: 4.16 vs 4.18, 6144: 3.16 vs 3.26, 4096: 1.94 vs 2.01)
 static int pick_w(const mi_gp_handle* h, int rem, int cap) {
   int W = h->cfg.panel_tiles;
   if (W <= 0) {

@@ -511,7 +511,8 @@ class GPMCMC(ConsumersMixin):
                     # the caller's own handle gets its previous settings back afterwards (library defaults: look-ahead by
                     # size = 1, super-panel width by size = 0)
                     before = (h.get_option(2, 0), h.get_option(0, 1))
-                    h.set_option(2, 4)
+                    if ntc <= 60:  # (api_gp.hip NARROW_PANELS_MAX_TILES: above it both schedules use 8-tile super-panels)
+                        h.set_option(2, 4)
                     h.set_option(0, 0)
                 try:
                     lik = self._warp_likelihood(h, x, y, xin, iwgp, cwgp) if (iwgp or cwgp) else None

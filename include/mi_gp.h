@@ -144,7 +144,7 @@ int mi_gp_predict_grad(mi_gp_handle* h, const double* Xnew_dev, int m, double* w
  *      kernel (default 1: a last round with few tiles costs a whole round; sharded N=65536 on one rank 1.52 -> 1.47 s)
  *   14 band height (tile rows) of the band-column-major tile order of uniform-k trapezoid launches (default 8, 0 = row-major)
  *   16 panel-stream GEMM launches raise their waves' issue priority (s_setprio 3) against the bulk update's (default 1)
- *   18 tiles of a bulk update that run one workgroup per CU beside the panel chain, the rest two per CU (default 2048, 0: no split)
+ *   18 tiles of a bulk update that run one workgroup per CU beside the panel chain, the rest two per CU (default 1536, 0: no split)
  *   19 ... only when at least this many tiles remain for the second part (default 1024)
  *   20 trailing tile columns from which the next super-panel's update rides at the head of the trailing update's tile
  *      enumeration instead of in launches of its own (default 72, 0: never)
@@ -158,7 +158,7 @@ int mi_gp_predict_grad(mi_gp_handle* h, const double* Xnew_dev, int m, double* w
  *      for the next-panel update is a poll at the end of the leaf in front of the first reader (N = 4096 1.995 -> 1.965 ms).
  *      A poll that sees nothing for seconds gives up and the evaluation returns -2.
  * 8, 14, 16, 18, 19, 21, 24 and 26 only change scheduling (bit-identical results); 20 moves tiles between the two GEMM kernels (same k order); 2, 4-7, 9 regroup sums (agreement to rounding), and so does 0 where
- * it changes the super-panel width (20 to 64 tile columns).
+ * it changes the super-panel width (20 to 60 tile columns).
  * Unknown ids return -1.  (Round 1's options 1, 3, 10-13 -- GEMM variants, hipGraph replay, persistent bulk kernels,
  * exclusive leaf, fused leaf + strip -- are gone with the code they selected.) */
 int mi_gp_set_option(mi_gp_handle* h, int what, int value);

@@ -106,6 +106,6 @@ def test_ragged_large_size_through_the_split_and_merged_launches():
         for k, v in opts.items():
             gp.set_option(k, v)
         assert gp.lml(theta) == v0, opts
-        for k, v in {18: 2048, 19: 1024, 20: 72, 21: 8, 24: 1, 26: 2}.items():
+        for k, v in {18: 1536, 19: 1024, 20: 72, 21: 8, 24: 1, 26: 2}.items():
             gp.set_option(k, v)
     gp.close()

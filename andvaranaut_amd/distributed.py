@@ -216,8 +216,15 @@ class DistGP:
             # never waits for them on its compute streams, only before it stages into that buffer again (a receive into it
             # is ordered behind them on the transport's own stream anyway).
             sends = [None, None]
+            # (Only RCCL runs a communicator's collectives strictly one after the other.  gloo -- the tests' transport -- may
+            # run two at once: there a later receive into a buffer could overtake this rank's own send out of it to a slow
+            # peer, so with any other backend the owner waits for its sends at once, as it did until round 4.)
+            lazy_sends = (not self.collective) or dist.get_backend() == "nccl"
             work = self._exchange(0)  # panel 0 was staged on the main stream by its owner
             if owner(0) == self.rank:
+                if work is not None and not lazy_sends:
+                    work.wait()
+                    work = None
                 sends[0], work = work, None
             # the stream the owner's chain runs on (mi_gp_shard option 3): the side stream beside the bulk update on one
             # rank, the main stream ahead of it on several
@@ -248,6 +255,9 @@ class DistGP:
                         # piece by piece behind its staging (mi_gp_shard_wait_piece), not behind the later columns'
                         # factorisation or the bulk update
                         sends[jn % 2] = self._exchange(jn)
+                        if sends[jn % 2] is not None and not lazy_sends:
+                            sends[jn % 2].wait()
+                            sends[jn % 2] = None
                 if _keep:
                     self._keep_panel(j, self.P[j % 2])
                     if chain_stream is not main:

@@ -15,7 +15,8 @@
 //                       two chunks ahead, registers -> LDS one chunk ahead, MFMA operand fragments are double-buffered in
 //                       registers one k4-step ahead, and sched_group_barrier spreads the memory instructions between
 //                       the 64 MFMAs of a chunk.
-//   gemm_f64_kernel_s : the same schedule on 64x64 tiles for launches with too few 128x128 tiles to fill the chip.
+//   gemm_f64_kernel_s : the same schedule on 64x64 tiles for launches with too few 128x128 tiles to fill the chip; its
+//                       row-major operands are fetched as whole 128-byte row segments and stored XOR-swizzled (round 4).
 //
 // They serve: K3 Cholesky trailing / panel updates (NT, lower), K7 triangular
 // inverse levels (NN with triangular k-ranges) and L^-T L^-1 (TN), K8 predict triangular-solve updates (NT).
@@ -130,6 +131,14 @@ constexpr int BKB = 16;
 constexpr int OPER_B = BKB * LDS_LD;
 constexpr int NT_B = 256;
 constexpr int NQB = TILE * BKB / 2 / NT_B;  // 4
+// Coalesced row-major operand loads + XOR-swizzled LDS image (chunk_offsets), as in the 64x64-tile kernel, where they are
+// worth 1.3 % of an N = 16384 evaluation.  OFF here: this kernel needs half the bytes per flop and is not bound by what a CU
+// can fetch -- with the swizzle an evaluation measures 25.72-25.89 ms against 25.81-25.84 without (same box, alternating),
+// and the eight fragment bases instead of two cost 6 more spilled VGPRs (10 instead of 4) at the 256-register ceiling.
+#ifndef MIGP_SWZ_B
+#define MIGP_SWZ_B 0
+#endif
+constexpr bool SWZ = MIGP_SWZ_B != 0;
 
 template <bool KMAJOR>
 __device__ __forceinline__ void chunk_offsets(long ld, int tid, unsigned& goff, unsigned& loff, long& gstride) {
@@ -138,6 +147,12 @@ __device__ __forceinline__ void chunk_offsets(long ld, int tid, unsigned& goff, 
     goff = (unsigned)((k * ld + 2 * xc) * 8);
     loff = (unsigned)((k * LDS_LD + 2 * xc) * 8);
     gstride = 4 * ld * 8;
+  } else if (SWZ) {
+    // coalesced row segments + XOR-swizzled image, as in the 64x64-tile kernel (vs::chunk_offsets has the reasoning)
+    const int kc = tid & 7, row = tid >> 3;  // x = 32q + (t>>3), k = 2 (t&7)
+    goff = (unsigned)((row * ld + 2 * kc) * 8);
+    loff = (unsigned)(((2 * kc) * LDS_LD + (row ^ (2 * kc))) * 8);
+    gstride = 32 * ld * 8;
   } else {
     const int xl = tid & 15, kc = (tid >> 4) & 7, xh = tid >> 7;  // x = 32q + 16*(t>>7) + (t&15)
     goff = (unsigned)(((xh * 16 + xl) * ld + 2 * kc) * 8);
@@ -249,12 +264,18 @@ __global__ __launch_bounds__(vb::NT_B, 2) void gemm_f64_kernel_b(GemmParams p) {
   __syncthreads();
 
   const int kq = lane >> 4, l15 = lane & 15;
-  const double* a_ptr = As + kq * LDS_LD + wr * 64 + l15;
-  const double* b_ptr = Bs + kq * LDS_LD + wc * 64 + l15;
+  const double* a_ptr[4];  // per k4-step: the row-major operands' images are swizzled by the k pair, k & 14 = 4 kk + (kq & 2)
+  const double* b_ptr[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    const int sa = (vb::SWZ && !A_KMAJOR) ? (4 * kk + (kq & 2)) : 0, sb = (vb::SWZ && !B_KMAJOR) ? (4 * kk + (kq & 2)) : 0;
+    a_ptr[kk] = As + kq * LDS_LD + wr * 64 + (l15 ^ sa);
+    b_ptr[kk] = Bs + kq * LDS_LD + wc * 64 + (l15 ^ sb);
+  }
   double af[2][4], bf[2][4];
   auto load_frags = [&](int set, int boff, int kk) {
-    const double* ap = a_ptr + boff + kk * 4 * LDS_LD;
-    const double* bp = b_ptr + boff + kk * 4 * LDS_LD;
+    const double* ap = a_ptr[kk] + boff + kk * 4 * LDS_LD;
+    const double* bp = b_ptr[kk] + boff + kk * 4 * LDS_LD;
 #pragma unroll
     for (int a = 0; a < 4; ++a) af[set][a] = ap[16 * a];
 #pragma unroll
@@ -384,6 +405,10 @@ constexpr int LDS_S = 80;  // 64 + 16: odd k rows land 16 bank-pairs away from e
 constexpr int OPER_S = BKS * LDS_S;
 constexpr int NQS = TS * BKS / 2 / 256;  // 2
 constexpr int NBUF = 3;                  // LDS buffers per operand (see the pipeline note in the kernel)
+#ifndef MIGP_SWZ_S
+#define MIGP_SWZ_S 1
+#endif
+constexpr bool SWZ = MIGP_SWZ_S != 0;    // coalesced row-major operand loads + XOR-swizzled LDS image (chunk_offsets)
 
 template <bool KMAJOR>
 __device__ __forceinline__ void chunk_offsets(long ld, int tid, unsigned& goff, unsigned& loff, long& gstride) {
@@ -392,6 +417,16 @@ __device__ __forceinline__ void chunk_offsets(long ld, int tid, unsigned& goff, 
     goff = (unsigned)((k * ld + 2 * xc) * 8);
     loff = (unsigned)((k * LDS_S + 2 * xc) * 8);
     gstride = 8 * ld * 8;
+  } else if (SWZ) {
+    // Eight consecutive lanes fetch ONE row's 128-byte chunk segment (a whole cache line per row, 8 rows per wave
+    // instruction) instead of sixteen lanes fetching 16 bytes of sixteen different rows.  The k-major LDS image is then
+    // written with the column XOR-swizzled by the k pair, col = x ^ (k & 14): a wave's 16-lane write groups (8 k pairs x 2
+    // rows) hit 16 distinct bank pairs, and a fragment read (16 consecutive x at one k, XORed with a constant below 16)
+    // stays a permutation of its aligned 16-column block, so the read side keeps its conflict-free pattern.
+    const int kc = tid & 7, row = tid >> 3;  // x = 32q + (t>>3), k = 2 (t&7)
+    goff = (unsigned)((row * ld + 2 * kc) * 8);
+    loff = (unsigned)(((2 * kc) * LDS_S + (row ^ (2 * kc))) * 8);
+    gstride = 32 * ld * 8;
   } else {
     const int xl = tid & 15, kc = (tid >> 4) & 7, xh = tid >> 7;  // x = 32q + 16*(t>>7) + (t&15)
     goff = (unsigned)(((xh * 16 + xl) * ld + 2 * kc) * 8);
@@ -539,14 +574,22 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel_s(GemmParams p) {
   }
   __syncthreads();
 
-  const double* a_ptr = As + kq * LDS_S + wr * 32 + l15;
-  const double* b_ptr = Bs + kq * LDS_S + wc * 32 + l15;
+  // fragment bases per k4-step: the row-major operands' images are swizzled by the k pair (vs::chunk_offsets), k & 14 =
+  // 4 kk + (kq & 2) for k = 4 kk + kq
+  const double* a_ptr[4];
+  const double* b_ptr[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    const int sa = (vs::SWZ && !A_KMAJOR) ? (4 * kk + (kq & 2)) : 0, sb = (vs::SWZ && !B_KMAJOR) ? (4 * kk + (kq & 2)) : 0;
+    a_ptr[kk] = As + kq * LDS_S + wr * 32 + (l15 ^ sa);
+    b_ptr[kk] = Bs + kq * LDS_S + wc * 32 + (l15 ^ sb);
+  }
   // Same schedule as the 128x128 kernel at a quarter of the tile: branch-free chunk body, operand fragments double-buffered
   // one k4-step ahead, and the chunk's 4 global loads / 8 fragment reads / LDS writes spread between its 16 MFMAs.
   double fa[2][2], fb[2][2];
   auto load_frags = [&](int set, int boff, int kk) {
-    const double* ap = a_ptr + boff + kk * 4 * LDS_S;
-    const double* bp = b_ptr + boff + kk * 4 * LDS_S;
+    const double* ap = a_ptr[kk] + boff + kk * 4 * LDS_S;
+    const double* bp = b_ptr[kk] + boff + kk * 4 * LDS_S;
     fa[set][0] = ap[0]; fa[set][1] = ap[16]; fb[set][0] = bp[0]; fb[set][1] = bp[16];
   };
   if (nchunk > 0) load_frags(0, 0, 0);

@@ -409,6 +409,9 @@ constexpr int NBUF = 3;                  // LDS buffers per operand (see the pip
 #define MIGP_SWZ_S 1
 #endif
 constexpr bool SWZ = MIGP_SWZ_S != 0;    // coalesced row-major operand loads + XOR-swizzled LDS image (chunk_offsets)
+#ifndef MIGP_XCD_MAP_S
+#define MIGP_XCD_MAP_S 1
+#endif
 
 template <bool KMAJOR>
 __device__ __forceinline__ void chunk_offsets(long ld, int tid, unsigned& goff, unsigned& loff, long& gstride) {
@@ -467,12 +470,20 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel_s(GemmParams p) {
 
   int ti, tj;
   int rc, cc;  // C tile row / column in 64-row units (differ from the operand rows ti / tj only in panel-list mode)
+  // XCD-aware block -> tile map for uniform-k launches, as in the 128x128-tile kernel: workgroup b runs on XCD b % 8, and
+  // each XCD takes a CONTIGUOUS range of the enumeration, so the tiles of one tile row (consecutive indices: they share
+  // their A rows) meet in one L2 instead of eight.
+  int bid = (int)blockIdx.x;
+  if (MIGP_XCD_MAP_S && p.kmode == 0) {
+    const int nblk = (int)gridDim.x, x = bid & 7, q = nblk >> 3, r = nblk & 7;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+  }
   if (p.pl) {
-    // panel-list launch (or the tail of one): this workgroup is one quadrant of 128x128 tile sub_base + blockIdx.x / 4
+    // panel-list launch (or the tail of one): this workgroup is one quadrant of 128x128 tile sub_base + bid / 4
     int ra, rb, prc, pcc;
     bool diag;
-    const int quad = (int)blockIdx.x & 3;
-    list_tile(p, p.sub_base + ((int)blockIdx.x >> 2), ra, rb, prc, pcc, diag);
+    const int quad = bid & 3;
+    list_tile(p, p.sub_base + (bid >> 2), ra, rb, prc, pcc, diag);
     if (diag && quad == 1) return;  // the quadrant above the diagonal of a diagonal tile
     ti = 2 * ra + (quad >> 1);
     tj = 2 * rb + (quad & 1);
@@ -482,7 +493,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel_s(GemmParams p) {
     if (p.sub_base >= 0) {
       // tail of a 128x128-tile launch: this workgroup is one quadrant of parent tile sub_base + blockIdx.x / 4
       int pti, ptj;
-      const int pidx = p.sub_base + ((int)blockIdx.x >> 2), quad = (int)blockIdx.x & 3;
+      const int pidx = p.sub_base + (bid >> 2), quad = bid & 3;
       if (p.fc > 0) tile_from_index_fc(p.sub_mt, p.sub_nt, p.fc, p.band, pidx, pti, ptj);
       else if (p.band > 0 && p.tri) tile_from_index_banded(p.tri, p.sub_mt, p.sub_nt, pidx, p.band, pti, ptj);
       else tile_from_index(p.tri, p.sub_nt, pidx, pti, ptj);
@@ -490,7 +501,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel_s(GemmParams p) {
       tj = 2 * ptj + (quad & 1);
       if (p.tri && tj > ti) return;  // the quadrant above the diagonal of a diagonal parent tile
     } else {
-      tile_from_index(p, blockIdx.x, ti, tj);
+      tile_from_index(p, bid, ti, tj);
     }
     if (p.kmode == 2) ti = p.mt - 1 - ti;
     if (p.kmode == 4 && !p.tri) { tj = p.nt - 1 - (int)blockIdx.x / p.mt; ti = (int)blockIdx.x % p.mt; }  // longest-k columns first (LPT order)

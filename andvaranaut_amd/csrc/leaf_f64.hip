@@ -780,14 +780,25 @@ __device__ __forceinline__ void trsm_strip128_body(const double* __restrict__ mi
   }
 }
 
+#ifndef MIGP_XCD_MAP_STRIP
+#define MIGP_XCD_MAP_STRIP 1
+#endif
 // one launch serves `gridDim.y` independent (M, B) pairs: M at minv + y * 16384, B at B + y * strideB
 template <int RG>
 __global__ __launch_bounds__(256) void trsm_strip128_kernel(const double* __restrict__ minv, double* __restrict__ B, long ldb,
                                                              long strideB, long sminv2, long sB2) {
   __builtin_amdgcn_s_setprio(3);
+  // Row groups -> XCDs in contiguous ranges (workgroup b runs on XCD b % 8), the same way the GEMM kernels map their tile
+  // rows: the update that follows reads this strip's rows, and the next strip reads what that update wrote, out of the L2
+  // that already holds them.
+  int blk = (int)blockIdx.x;
+  if (MIGP_XCD_MAP_STRIP) {
+    const int nblk = (int)gridDim.x, x = blk & 7, q = nblk >> 3, r = nblk & 7;
+    blk = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (blk >> 3);
+  }
   // blockIdx.z: problem of a batched evaluation (second batch level)
   trsm_strip128_body<RG>(minv + (long)blockIdx.y * (LEAF * LEAF) + (long)blockIdx.z * sminv2,
-                         B + (long)blockIdx.y * strideB + (long)blockIdx.z * sB2, ldb, blockIdx.x);
+                         B + (long)blockIdx.y * strideB + (long)blockIdx.z * sB2, ldb, blk);
 }
 
 constexpr size_t LEAF_LDS_BYTES = sizeof(double) * (LEAF_ELEMS + 2 * SB * SB + LEAF + 3);

@@ -218,10 +218,29 @@ def analyse(insts, entry_defined, exec_aware=True):
         if i.mn == "s_cbranch_execz" and i.target in addr2idx:
             t = addr2idx[i.target]
             e, has_vec = t, False
+            zero = set()  # SGPRs that hold an EXEC mask saved INSIDE the window, i.e. zero
             while e < len(insts):
                 j = insts[e]
                 if is_exec_write(j):
+                    # The window ends only at an EXEC write that can ENABLE lanes.  exec &= x cannot; s_and_saveexec saves the
+                    # current (zero) mask into its destination, and OR-ing such a saved zero back cannot either.  (hipcc emits
+                    # `s_cbranch_execz +1; s_branch +1` pairs at kernel entry and chains of s_and_saveexec / s_or_b64 exec
+                    # around predicated loads: without this rule everything behind them looked unwritten.)
+                    if j.mn.startswith("s_and_saveexec") or j.mn.startswith("s_andn2_saveexec"):
+                        zero.update(regs_of(j.ops[0]))
+                        has_vec = has_vec or False
+                        e += 1
+                        continue
+                    if j.mn in ("s_and_b64", "s_andn2_b64", "s_and_b32", "s_andn2_b32") and j.ops and j.ops[0] == "exec" and "exec" in j.ops[1:]:
+                        e += 1
+                        continue
+                    if j.mn in ("s_or_b64", "s_or_b32") and len(j.ops) == 3 and j.ops[0] == "exec" and \
+                            all(o == "exec" or (regs_of(o) and set(regs_of(o)) <= zero) for o in j.ops[1:]):
+                        e += 1
+                        continue
                     break
+                if not is_vector(j):
+                    zero.difference_update(defs_uses(j)[0])  # a scalar write over a saved mask: no longer known to be zero
                 if j.mn.startswith("s_cbranch") or j.mn in ("s_branch", "s_endpgm", "s_setpc_b64", "s_barrier"):
                     e = None
                     break

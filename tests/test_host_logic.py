@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import scipy.stats as st
 
-from conftest import load_json
+from conftest import ROOT, load_json
 from oracle import gp_oracle as orc
 
 
@@ -528,3 +528,44 @@ def test_batched_evaluator_rendezvous_serves_every_client_its_own_row():
     for t in ts:
         t.join(timeout=30)
     assert len(errs) == 2
+
+
+def test_sharded_timeline_model_orders_its_three_send_modes():
+    """tools/emulate_rank.predict(): the timeline that turns per-step times of emulated ranks into a W-rank prediction
+    (a model, not a measurement).  On synthetic step tables: (i) with a free link the prediction is the
+    serial owner chain plus the bulk updates of the slowest rank; (ii) a piece-wise send is never later than the send
+    behind the whole panel and never earlier than a free link; (iii) when the pieces are staged evenly and a piece's
+    transfer is shorter than the gap to the next piece, only the LAST piece's transfer is exposed."""
+    import importlib.util
+    import os
+
+    import numpy as np
+
+    spec = importlib.util.spec_from_file_location("emulate_rank", os.path.join(ROOT, "tools", "emulate_rank.py"))
+    em = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(em)
+    world, pwt, npan, N = 4, 4, 16, 16 * 512
+    recs = []
+    for r in range(world):
+        steps = np.zeros((npan + 1, 4))
+        pieces = np.zeros((npan + 1, pwt))
+        for j in range(npan):
+            if (j + 1) % world == r and j + 1 < npan:
+                steps[j, 0], steps[j, 1] = 0.2, 0.8            # update, factor (+ staging) of panel j + 1
+                pieces[j] = 0.2 + 0.8 * np.arange(1, pwt + 1) / pwt   # staged evenly through the factorisation
+            steps[j, 3] = 0.5                                  # this rank's bulk update of step j
+        if r == 0:
+            steps[npan, 1] = 0.8
+            pieces[npan] = 0.8 * np.arange(1, pwt + 1) / pwt
+        recs.append({"rank": r, "npan": npan, "steps": steps.tolist(), "pieces": pieces.tolist()})
+    free = em.predict(world, recs, N, pwt, True, link_gbps=1e9, pipelined=True)["predicted_ms"]
+    whole = em.predict(world, recs, N, pwt, True, link_gbps=100.0, pipelined=False)
+    piece = em.predict(world, recs, N, pwt, True, link_gbps=100.0, pipelined=True)
+    assert free <= piece["predicted_ms"] <= whole["predicted_ms"]
+    assert piece["sum_link_ms_behind_the_chain"] < whole["sum_link_ms_behind_the_chain"]
+    # (iii): at 100 GB/s a piece of the first panel takes (N + 256) * 128 * 8 / 1e11 s = 0.087 ms < the 0.2 ms between pieces
+    p0 = (N + 128 + 128) * 128 * 8 / 100e9 * 1e3
+    exposed_first = em.predict(world, [recs[0]] + recs[1:], N, pwt, True, link_gbps=100.0, pipelined=True)
+    assert abs(whole["sum_link_ms"] / piece["sum_link_ms"] - 1.0) < 1e-12  # same bytes either way
+    assert piece["sum_link_ms_behind_the_chain"] <= (npan + 1) * p0 + 1e-9  # at most one piece per panel is exposed
+    assert exposed_first["predicted_ms"] == piece["predicted_ms"]            # deterministic

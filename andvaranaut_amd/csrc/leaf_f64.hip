@@ -44,7 +44,7 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
 }
 
 #ifdef LEAF_STAMPS
-__device__ unsigned long long g_leaf_stamps[16];
+__device__ unsigned long long g_leaf_stamps[32];
 #define LEAF_STAMP(i)                                                                  \
   do {                                                                                 \
     if (threadIdx.x == 0) {                                                            \
@@ -69,10 +69,19 @@ __device__ unsigned long long g_leaf_stamps[16];
 #define LEAF_STAMP1(i)
 #endif
 
+// LDS words the waves of the leaf meet through, as LDS instructions: through a generic `volatile int*` the compiler emits
+// FLAT loads / stores with system-scope cache bits and vmcnt waits (round 4's listing), and a workgroup-scope fence also
+// waits for the wave's outstanding GLOBAL stores (the column stream-out).
+typedef __attribute__((address_space(3))) int lds_int_t;
+__device__ __forceinline__ int lds_load(volatile lds_int_t* p) { return *p; }
+__device__ __forceinline__ void lds_store(volatile lds_int_t* p, int v) { *p = v; }
+__device__ __forceinline__ void lds_add(lds_int_t* p, int v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 __device__ __forceinline__ void wave_lds_fence() {
-  // order this wave's LDS writes before its later LDS reads (DS ops execute in order per wave;
-  // this only stops the compiler from reordering / caching across the point)
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  // this wave's LDS operations have completed (they execute in order; the CU's LDS is coherent for the workgroup), and
+  // the compiler moves no memory access across the point
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
 }
 
@@ -124,70 +133,118 @@ __device__ __forceinline__ double quad_bcast(double v) {
   const int hi = __builtin_amdgcn_update_dpp(0, (int)(u >> 32), G * 0x55, 0xf, 0xf, false);
   return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
 }
-// Forward substitution X = B L16^-T for 16 rows on one wave: lane 4*row + g owns columns g, g+4, g+8, g+12.
-template <int K>
-struct QuadSolve {
-  // lt[K][i] = L16[4i+g][K] and inv[i] = 1/L16[4i+g][4i+g] are preloaded so that no LDS latency sits on the chain
-  static __device__ __forceinline__ void run(double (&x)[4], const double (&lt)[16][4], const double (&inv)[4], int g) {
-    const double xk = quad_bcast<(K & 3)>(x[K >> 2] * inv[K >> 2]);
-    if (g == (K & 3)) x[K >> 2] = xk;
-#pragma unroll
-    for (int i = K >> 2; i < 4; ++i) {
-      // column 4i+g is updated only if it lies right of K (lanes of slot K>>2 with g <= K&3 are done)
-      if (i > (K >> 2) || g > (K & 3)) x[i] = __builtin_fma(-xk, lt[K][i], x[i]);
-    }
-    QuadSolve<K + 1>::run(x, lt, inv, g);
+// ---- The chain wave's elimination (round 5).
+// Wave 0 holds NA register panels of 16 columns: a[0] = the 16x16 diagonal block, row (lane & 15) per lane (the four 16-lane
+// DPP rows mirror each other), a[1..] = rows BELOW the block, one per lane.  One square-root-free elimination step J is
+//   w_i = -a_i[J] / p_J ;  a_i[C] += w_i * L~[C][J]  (C > J),  L~[C][J] = a_0[J] of lane C, fetched by the row_newbcast:C
+// of v_fmac_f64_dpp -- the SAME instruction updates the diagonal block and the rows below it, so the triangular solve of
+// the rows below (rounds 1-4: a separate substitution after the factor, 2.1k cycles per 16 columns on the chain, and a
+// 2.4k-cycle one-row-per-thread substitution on the helper waves) rides in the issue slots of the factorisation.
+// Rounds 1-4 also left the schedule to the compiler, which emitted, per pivot, all fillers, THEN the pivot broadcast and
+// the whole reciprocal chain (disassembly of round 4: ~245 cycles per pivot against ~70 of dependent latency).  Here the
+// fillers of step J - 1 are issued inside the latency gaps of step J's chain (rcp 20 cycles, every dependent fp64 op 8,
+// the DPP broadcast 17; an independent fp64 instruction issues every ~5.3: tools/probe_valu_f64.hip), pinned by
+// sched_barriers.  The reciprocal is the hardware seed y0 (2^-24) times (1 + e + e^2), e = 1 - p y0: relative error e^3 =
+// 2^-73, three dependent operations behind the seed instead of five.
+#define MIGP_SB0() __builtin_amdgcn_sched_barrier(0)
+template <int I, int N, class F>
+__device__ __forceinline__ void lt_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>());
+    lt_static_for<I + 1, N>(f);
   }
-};
-template <>
-struct QuadSolve<16> {
-  static __device__ __forceinline__ void run(double (&)[4], const double (&)[16][4], const double (&)[4], int) {}
-};
-
-// One elimination step of the 16x16 diagonal sub-block held one row per lane (a[c], c = 0..15):
-// square-root-free form, a_rc -= (a_rj / p_j) * a_cj for c > j, column j+1 first so that the next
-// pivot's reciprocal chain starts as early as possible.
-template <int J, int C>
-struct ElimCols {
-  static __device__ __forceinline__ void run(double (&a)[16], double negw) {
-    fmac_rowbcast<C>(a[C], a[J], negw);
-    ElimCols<J, C + 1>::run(a, negw);
-  }
-};
-template <int J>
-struct ElimCols<J, 16> {
-  static __device__ __forceinline__ void run(double (&)[16], double) {}
-};
-template <int J>
-struct ElimStep {
-  static __device__ __forceinline__ void run(double (&a)[16], double p, int& bad) {
-    if (!(p > 0.0) && bad == 0) bad = J + 1;
-    const double negw = -a[J] * fast_rcp(p);
-    fmac_rowbcast<J + 1>(a[J + 1], a[J], negw);
-    const double pn = mov_rowbcast<J + 1>(a[J + 1]);
-    ElimCols<J, J + 2>::run(a, negw);
-    ElimStep<J + 1>::run(a, pn, bad);
-  }
-};
-template <>
-struct ElimStep<15> {
-  static __device__ __forceinline__ void run(double (&)[16], double p, int& bad) {
-    if (!(p > 0.0) && bad == 0) bad = 16;
-  }
-};
+}
+namespace ch {
+// The chain in `asm volatile`: volatile statements keep their source order, so the schedule below IS the instruction order
+// (arithmetic left to the compiler floats: instruction selection puts an unchained multiply next to its first user, whatever
+// sched_barriers stand in between -- the first form of this round had the three multiplications in front of e0).  Wait
+// states the hardware does not interlock and the compiler cannot see inside asm: a transcendental result needs one
+// instruction before its first VALU reader (s_nop 0 behind v_rcp_f64), a DPP read two behind the VALU write of its
+// operand (callers; tests/test_dpp_hazard.py checks the library).
 template <int C>
-struct ScaleCols {
-  // l[C] = a[C] * rs of lane C: ONE dpp fmac into a zeroed accumulator (round 1: broadcast move + multiply, 25 cycles)
-  static __device__ __forceinline__ void run(const double (&a)[16], double rs, double (&l)[16]) {
-    l[C] = 0.0;
-    fmac_rowbcast<C>(l[C], rs, a[C]);
-    ScaleCols<C + 1>::run(a, rs, l);
+__device__ __forceinline__ void fmac_bc(double& acc, double src, double mul) {
+  asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "n"(C));
+}
+template <int C>
+__device__ __forceinline__ double mov_bc(double src) {  // two instructions since src was written: the caller's job
+  double out;
+  asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf\n\ts_nop 0" : "=v"(out) : "v"(src), "n"(C));
+  return out;
+}
+template <int C>
+__device__ __forceinline__ double mov_bc_padded(double src) {
+  double out;
+  asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf\n\ts_nop 0" : "=v"(out) : "v"(src), "n"(C));
+  return out;
+}
+__device__ __forceinline__ double a_rcp(double p) {
+  double y;
+  asm volatile("v_rcp_f64 %0, %1\n\ts_nop 0" : "=v"(y) : "v"(p));
+  return y;
+}
+__device__ __forceinline__ double a_one_minus(double p, double y) {  // 1 - p y
+  double e;
+  asm volatile("v_fma_f64 %0, -%1, %2, 1.0" : "=v"(e) : "v"(p), "v"(y));
+  return e;
+}
+__device__ __forceinline__ double a_mul(double x, double y) {
+  double t;
+  asm volatile("v_mul_f64 %0, %1, %2" : "=v"(t) : "v"(x), "v"(y));
+  return t;
+}
+__device__ __forceinline__ double a_nq(double e) {  // -(e + e^2)
+  double q;
+  asm volatile("v_fma_f64 %0, -%1, %1, -%1" : "=v"(q) : "v"(e));
+  return q;
+}
+__device__ __forceinline__ double a_fma_negc(double t, double q) {  // t q - t
+  double w;
+  asm volatile("v_fma_f64 %0, %1, %2, -%1" : "=v"(w) : "v"(t), "v"(q));
+  return w;
+}
+// fillers [LO, HI) of elimination step JP: a[i][C] += bcast_C(a[0][JP]) * w[i] for C = JP + 2 .. 15, enumerated C-major
+template <int JP, int NA, int LO, int HI>
+__device__ __forceinline__ void fillers(double (&a)[NA][16], const double (&w)[NA]) {
+  lt_static_for<LO, HI>([&](auto Ic) {
+    constexpr int idx = decltype(Ic)::value, C = JP + 2 + idx / NA, i = idx % NA;
+    fmac_bc<C>(a[i][C], a[0][JP], w[i]);
+  });
+}
+template <int J, int NA>
+struct Step {
+  // p: pivot J, broadcast; wp: the multipliers of step J - 1, whose fillers (columns J + 1 .. 15) are issued here, behind
+  // the reciprocal seed.  The columns stay UNNORMALISED (X~ = a): the rank-16 updates of the trailing tiles are
+  // tile -= (X~ D^-1) X~^T, so nothing on the chain waits for the reciprocal square roots of the pivots (rounds 1-4 and the
+  // first form of this round normalised on the chain: 1.7k cycles per 16 columns) -- the helpers normalise a column block
+  // an iteration later.
+  static __device__ __forceinline__ void run(double (&a)[NA][16], double p, const double (&wp)[NA]) {
+    constexpr int NF = J >= 1 ? NA * (15 - J) : 0;              // fillers of step J - 1
+    constexpr int want_fm = NA >= 3 ? 0 : 3 - NA;              // two instructions between the critical fmac and the DPP read of its result
+    constexpr int n_fm = NF - 1 >= want_fm ? want_fm : (NF - 1 > 0 ? NF - 1 : 0);
+    constexpr int n1 = NF - n_fm;                              // behind the reciprocal seed (20 cycles); filler 0 (the next pivot's column) is here
+    if constexpr (J < 15) {
+      const double y0 = a_rcp(p);
+      fillers<J - 1, NA, 0, n1>(a, wp);
+      const double e0 = a_one_minus(p, y0);
+      double t[NA], w[NA];
+      t[0] = a_mul(a[0][J], y0);
+      const double nq = a_nq(e0);
+#pragma unroll
+      for (int i = 1; i < NA; ++i) t[i] = a_mul(a[i][J], y0);
+      w[0] = a_fma_negc(t[0], nq);
+#pragma unroll
+      for (int i = 1; i < NA; ++i) w[i] = a_fma_negc(t[i], nq);
+      fmac_bc<J + 1>(a[0][J + 1], a[0][J], w[0]);
+      lt_static_for<1, NA>([&](auto Ic) { fmac_bc<J + 1>(a[decltype(Ic)::value][J + 1], a[0][J], w[decltype(Ic)::value]); });
+      fillers<J - 1, NA, n1, NF>(a, wp);
+      double pn;
+      if constexpr (NA - 1 + n_fm >= 2) pn = mov_bc<J + 1>(a[0][J + 1]);
+      else pn = mov_bc_padded<J + 1>(a[0][J + 1]);
+      Step<J + 1, NA>::run(a, pn, w);
+    }
   }
 };
-template <>
-struct ScaleCols<16> {
-  static __device__ __forceinline__ void run(const double (&)[16], double, double (&)[16]) {}
-};
+}  // namespace ch
 
 // 16x16 triangular inverse by substitution with the matrix held one ROW per lane (a[k] = L16[lane][k]): column c of the
 // inverse is solved by lane c, and L16[r][k] reaches it through the row_newbcast:R of v_fmac_f64_dpp -- no LDS reads on the
@@ -230,9 +287,18 @@ constexpr int TR[NTT] = {2, 3, 4, 5, 6, 7, 2, 3, 4, 5, 6, 7, 3, 4, 5, 6, 7, 4, 5
 constexpr int TC[NTT] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 6, 6, 7};
 constexpr bool live(int i, int jb) { return TR[i] == TC[i] ? jb <= TC[i] - 2 : jb <= TC[i] - 1; }
 constexpr bool last(int i, int jb) { return TR[i] == TC[i] ? jb == TC[i] - 2 : jb == TC[i] - 1; }
-constexpr bool needs(int w, int jb, int b) {  // does wave w read block row b of column block jb as an operand?
+// phase 0: the tiles that get their LAST update in iteration jb (block column jb + 1 and the diagonal tile jb + 2 -- what
+// wave 0 needs next); phase 1: the other live tiles
+constexpr bool sel(int i, int jb, int ph) { return live(i, jb) && (last(i, jb) == (ph == 0)); }
+// does wave w read block row b of column block jb in phase ph -- as an A operand (multipliers W) / as a B operand (X~)?
+constexpr bool needs_a(int w, int jb, int b, int ph) {
   for (int s = 0; s < 9; ++s)
-    if (live(3 * s + w, jb) && (TR[3 * s + w] == b || TC[3 * s + w] == b)) return true;
+    if (sel(3 * s + w, jb, ph) && TR[3 * s + w] == b) return true;
+  return false;
+}
+constexpr bool needs_b(int w, int jb, int b, int ph) {
+  for (int s = 0; s < 9; ++s)
+    if (sel(3 * s + w, jb, ph) && TC[3 * s + w] == b) return true;
   return false;
 }
 template <int I, int N, class F>
@@ -246,21 +312,25 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 // info: 0 = ok, else 1-based global index of the first non-positive (or NaN) pivot (atomicMin'd).
 //
-// Structure per 16-column block jb of the 128x128 leaf (all of it LDS resident):
-//  (A) wave 0 factors the 16x16 diagonal sub-block in REGISTERS: lane r owns row r, columns are
-//      eliminated in square-root-free (LDL^T) form so the per-pivot critical path is
-//      row-broadcast -> rcp -> mul -> fma (the rsqrt of all 16 pivots is taken once, in parallel, at
-//      the end); column values are broadcast inside v_fmac_f64_dpp row_newbcast, so one elimination
-//      is ONE instruction and there is no LDS round trip per pivot;
-//  (B) rows below: X = B L16^-T, one thread per row, column-oriented substitution in registers;
-//  (C) trailing update of the remaining lower tiles on fp64 MFMA (rank 16).
+// Structure (round 5) per 16-column block jb of the 128x128 leaf:
+//  wave 0 (the chain): holds the diagonal 16x16 block AND every row below it in registers (ch::Step above: two or three
+//      16-column panels per lane), eliminates the 16 columns, writes the unnormalised columns X~ to the LDS image and the
+//      multipliers W = -X~ D^-1 to a side buffer, raises `ready`, applies the rank-16 update  += W X~^T  to the NEXT
+//      diagonal tile on MFMA and waits for the helpers' urgent tiles -- the rest of the next panel.
+//  waves 1..3 (helpers): keep the 27 trailing 16x16 tiles in registers (namespace lt), left-looking.  Behind `ready` they
+//      first finish the tiles of the NEXT block column (their last update: results go to the LDS image, `urgent` is
+//      raised), then update the other live tiles while wave 0 already eliminates the next block, then normalise the
+//      PREVIOUS column block (L = X~ D^-1/2, in the LDS image and out to memory).  No workgroup barrier inside the loop:
+//      the sides meet through LDS counters.
 __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, long lda, double* __restrict__ minv,
                                                     int col0, int* __restrict__ info, double* smem, double* yrow) {
   double* S = smem;                     // packed lower block-trapezoid, see soff()
-  double* LdT2 = smem + LEAF_ELEMS;     // [2][16][16]  LdT[k][c] = L16[c][k] of diagonal sub-block jb (buffer jb & 1)
-  double* invd = LdT2 + 2 * SB * SB;    // [128] 1 / L[c][c]
-  volatile int* sync_w = reinterpret_cast<volatile int*>(invd + LEAF);  // [0] rows published by wave 0, [1] arrivals of waves 1..3,
-  // [2] arrivals of waves 1..3 inside the inverse phases, [3] Dinv_b ready (wave 1), [4] wave 0 done with column block jb
+  double* invd = smem + LEAF_ELEMS;     // [128] 1 / L[c][c]
+  double* pvt = invd + LEAF;            // [128] the pivots d_c (L[c][c]^2)
+  double* nrv = pvt + LEAF;             // [2][16] -1 / d_c of the current column block (buffer jb & 1)
+  lds_int_t* sync_a = (lds_int_t*)(nrv + 2 * SB);
+  volatile lds_int_t* sync_w = sync_a;  // [0] column blocks published by wave 0, [1] urgent
+  // arrivals of waves 1..3, [2] their load arrivals, [3] their lazy-phase arrivals
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: tile coordinates and soff() bases derived
@@ -270,113 +340,9 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
   if (threadIdx.x == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory");
   if (threadIdx.x == 64) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev1)::"memory");
 #endif
-
-  // load the lower block-trapezoid: wave 0 takes the first 16x16 block and starts factoring it while
-  // waves 1..3 stream in the other 4480 16-byte pieces (24 loads in flight per lane, one round trip)
   typedef double double2_t __attribute__((ext_vector_type(2)));
-  if (wave == 0) {
-    double2_t v[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int e = lane + 64 * u;  // 128 pieces of block row 0
-      v[u] = *reinterpret_cast<const double2_t*>(Ablk + (long)(e >> 3) * lda + 2 * (e & 7));
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int e = lane + 64 * u;
-      *reinterpret_cast<double2_t*>(S + soff(e >> 3) + 2 * (e & 7)) = v[u];
-    }
-    wave_lds_fence();
-  } else {
-    // row block b holds 16 rows x 8(b+1) pieces; compile-time b makes the div/mod cheap
-    const int t = tid - 64;
-    double2_t v[27];
-    int u = 0;
-#pragma unroll
-    for (int bb = 0; bb < 8; ++bb) {
-      const int per = 8 * (bb + 1), cnt = 16 * per, skip = (bb == 0) ? 128 : 0;  // block 0 belongs to wave 0
-#pragma unroll
-      for (int idx0 = skip; idx0 < cnt; idx0 += 192) {
-        const int idx = idx0 + t;
-        if (idx < cnt) v[u] = *reinterpret_cast<const double2_t*>(Ablk + (long)(16 * bb + idx / per) * lda + 2 * (idx % per));
-        ++u;
-      }
-    }
-    u = 0;
-#pragma unroll
-    for (int bb = 0; bb < 8; ++bb) {
-      const int per = 8 * (bb + 1), cnt = 16 * per, skip = (bb == 0) ? 128 : 0;
-#pragma unroll
-      for (int idx0 = skip; idx0 < cnt; idx0 += 192) {
-        const int idx = idx0 + t;
-        if (idx < cnt) *reinterpret_cast<double2_t*>(S + soff(16 * bb + idx / per) + 2 * (idx % per)) = v[u];
-        ++u;
-      }
-    }
-  }
-  // (A): factor the 16x16 diagonal sub-block jb in registers (wave 0; lanes 16..63 mirror lanes 0..15)
-  auto factor_diag = [&](int jb) {
-    const int j0 = jb * SB;
-    const int r = lane & 15;
-    double a[SB];
-    {
-      const double* row = S + soff(j0 + r) + j0;
-#pragma unroll
-      for (int c = 0; c < SB; ++c) a[c] = row[c];
-    }
-    int bad = 0;
-    ElimStep<0>::run(a, mov_rowbcast<0>(a[0]), bad);
-    if (bad != 0 && lane == 0) atomicMin(info, col0 + j0 + bad);
-    // normalise: L[r][c] = a[c] * rsqrt(p_c); lane c holds p_c = a[c]
-    double rs = fast_rsqrt(a[r]);
-    double l[SB];
-    dpp_settle(rs);  // rs was written by VALU just now: two wait states before the DPP reads below
-    ScaleCols<0>::run(a, rs, l);
-    double* row = S + soff(j0 + r) + j0;
-    double* LdT = LdT2 + (jb & 1) * SB * SB;
-#pragma unroll
-    for (int c = 0; c < SB; ++c) {
-      if (lane < SB && c <= r) {
-        row[c] = l[c];
-        LdT[c * SB + r] = l[c];
-      }
-    }
-    if (lane < SB) invd[j0 + r] = rs;
-  };
-  // (B) for one row: X = B * L16^-T by column-oriented forward substitution in registers
-  auto solve_row = [&](int jb, int rowidx) {
-    const int j0 = jb * SB;
-    const double* LdT = LdT2 + (jb & 1) * SB * SB;
-    double* row = S + soff(rowidx) + j0;
-    double x[SB];
-#pragma unroll
-    for (int c = 0; c < SB; ++c) x[c] = row[c];
-#pragma unroll
-    for (int k = 0; k < SB; ++k) {
-      x[k] *= invd[j0 + k];
-#pragma unroll
-      for (int c = k + 1; c < SB; ++c) x[c] = __builtin_fma(-x[k], LdT[k * SB + c], x[c]);
-    }
-#pragma unroll
-    for (int c = 0; c < SB; ++c) row[c] = x[c];
-  };
-  // (C) one 16x16 tile of the trailing update: S[r0.., c0..] -= X[r0..] X[c0..]^T with X = columns j0..j0+15
-  auto update_tile = [&](int j0, int r0, int c0) {
-    const int n = lane & 15, kq = lane >> 4;
-    double4_t acc;
-    double av[4], bv[4];
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-      av[s4] = S[soff(r0 + n) + j0 + 4 * s4 + kq];  // X[r0 + (l&15)][k = 4s + (l>>4)]
-      bv[s4] = S[soff(c0 + n) + j0 + 4 * s4 + kq];  // X[c0 + (l&15)][k]
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = S[soff(r0 + kq + 4 * r) + c0 + n];
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[s4], bv[s4], acc, 0, 0, 0);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) S[soff(r0 + kq + 4 * r) + c0 + n] = acc[r];
-  };
+  if (tid == 64) { sync_w[0] = 0; sync_w[1] = 0; sync_w[2] = 0; sync_w[3] = 0; }
+  __syncthreads();
 
   // tile (rb, cb) of the LDS image as MFMA operands / result:
   //   A operand: lane holds [16 rb + n][16 cb + 4 s + kq];  B operand: [16 rb + 4 s + kq][16 cb + n];  D: [16 rb + kq + 4 r][16 cb + n]
@@ -385,156 +351,311 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
 #pragma unroll
     for (int r = 0; r < 4; ++r) S[soff(16 * rb + kq + 4 * r) + 16 * cb + nn] = v[r];
   };
-  LEAF_STAMP(0);
-  if (tid == 64) { sync_w[0] = 0; sync_w[1] = 0; sync_w[2] = 0; sync_w[3] = 0; sync_w[4] = 0; }
-  if (wave == 0) factor_diag(0);
-  __syncthreads();
-  LEAF_STAMP(1);
-  // Register-resident trailing tiles of waves 1..3 (see namespace lt).  Per iteration a wave reads one operand set
-  // (4 doubles per lane) per block row it touches -- the same registers serve as the MFMA A operand of the tiles in that
-  // block row and as the B operand of the tiles in that block column -- and issues its live tiles' MFMAs interleaved
-  // (up to nine independent accumulators: full issue rate).  Round 2 until here: every tile went LDS -> registers -> LDS
-  // in every iteration, three or four at a time (0.7k cycles per tile; 12 LDS accesses per lane and tile instead of ~3).
-  double4_t tacc[9];
-  auto trailing = [&](auto JBc, auto Wc) {
-    constexpr int JB = decltype(JBc)::value, W = decltype(Wc)::value;
-    double op[8][4];
-    lt::static_for<1, 8>([&](auto Bc) {
-      constexpr int B = decltype(Bc)::value;
-      if constexpr (lt::needs(W, JB, B)) {
+
+  if (wave == 0) {
+    // ---------------------------------------------------------------- the chain
+    auto iteration = [&](auto NAc, int jb) {
+      constexpr int NA = decltype(NAc)::value;
+      const int j0 = jb * SB;
+      const int r16 = lane & 15;
+      int row[3];
+      bool valid[3];
+      row[0] = j0 + r16;
+      row[1] = j0 + SB + lane;
+      row[2] = j0 + SB + 64 + lane;
+      valid[0] = lane < SB;
+      valid[1] = row[1] < LEAF;
+      valid[2] = row[2] < LEAF;
+      double a[NA][16];
+      if (jb == 0) {  // straight from memory: the chain starts one global round trip after the launch
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) op[B][s4] = S[soff(16 * B + nn) + 16 * JB + 4 * s4 + kq];
+        for (int i = 0; i < NA; ++i) {
+          const double* src = Ablk + (long)(valid[i] ? row[i] : row[0]) * lda;
+#pragma unroll
+          for (int c = 0; c < SB; c += 2) {
+            const double2_t v = *reinterpret_cast<const double2_t*>(src + c);
+            a[i][c] = v.x;
+            a[i][c + 1] = v.y;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+          const double* src = S + soff(valid[i] ? row[i] : row[0]) + j0;
+#pragma unroll
+          for (int c = 0; c < SB; c += 2) {
+            const double2_t v = *reinterpret_cast<const double2_t*>(src + c);
+            a[i][c] = v.x;
+            a[i][c + 1] = v.y;
+          }
+        }
       }
-    });
+      LEAF_STAMP(0);
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        double w0[NA];
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4)
+        for (int i = 0; i < NA; ++i) w0[i] = 0.0;
+        ch::Step<0, NA>::run(a, ch::mov_bc_padded<0>(a[0][0]), w0);
+      }
+      LEAF_STAMP(24 + jb);
+      // lane c keeps the pivot d_c = a[0][c] (a run-time register index would put the panels into scratch) and -1 / d_c
+      double my_p = a[0][0];
+#pragma unroll
+      for (int c = 1; c < SB; ++c) my_p = (r16 == c) ? a[0][c] : my_p;
+      double my_nr;
+      {
+        const double y0 = __builtin_amdgcn_rcp(my_p);
+        const double e0 = __builtin_fma(-my_p, y0, 1.0);
+        const double nq = __builtin_fma(-e0, e0, -e0);
+        my_nr = __builtin_fma(y0, nq, -y0);
+      }
+      // X~ of the rows below the block, the pivots and their reciprocals first: the updates wait for them; the block's own
+      // rows are read by nobody before the normalisation
+#pragma unroll
+      for (int i = 1; i < NA; ++i) {
+        if (valid[i]) {
+          double* dst = S + soff(row[i]) + j0;
+#pragma unroll
+          for (int c = 0; c < SB; c += 2) {
+            double2_t v;
+            v.x = a[i][c];
+            v.y = a[i][c + 1];
+            *reinterpret_cast<double2_t*>(dst + c) = v;
+          }
+        }
+      }
+      pvt[j0 + r16] = my_p;  // (the four 16-lane rows write the same values)
+      nrv[(jb & 1) * SB + r16] = my_nr;
+      wave_lds_fence();
+      if (lane == 0) lds_store(sync_w + 0, jb + 1);
+      if (lane < SB) {
+        double* dst = S + soff(row[0]) + j0;
+#pragma unroll
+        for (int c = 0; c < SB; c += 2) {
+          double2_t v;
+          v.x = a[0][c];
+          v.y = a[0][c + 1];
+          *reinterpret_cast<double2_t*>(dst + c) = v;
+        }
+      }
+      LEAF_STAMP(2);
+    };
+    // rank-16 update of the next diagonal tile: S[r0.., r0..] -= (X~ D^-1) X~^T with the rows r0.. of columns j0..j0+15;
+    // four independent accumulators (a dependent fp64 MFMA follows its predecessor after ~250 cycles)
+    auto update_diag_tile = [&](int jb) {
+      const int j0 = jb * SB, r0 = j0 + SB;
+      const double* nr = nrv + (jb & 1) * SB;
+      const double4_t z4 = {0.0, 0.0, 0.0, 0.0};
+      double4_t acc, p1 = z4, p2 = z4, p3 = z4;
+      double av[4], bv[4];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        bv[s4] = S[soff(r0 + nn) + j0 + 4 * s4 + kq];
+        av[s4] = bv[s4] * nr[4 * s4 + kq];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = S[soff(r0 + kq + 4 * r) + r0 + nn];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], acc, 0, 0, 0);
+      p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1], p1, 0, 0, 0);
+      p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv[2], p2, 0, 0, 0);
+      p3 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bv[3], p3, 0, 0, 0);
+      acc = (acc + p1) + (p2 + p3);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) S[soff(r0 + kq + 4 * r) + r0 + nn] = acc[r];
+    };
+    for (int jb = 0; jb < LEAF / SB; ++jb) {
+      if (jb <= 2) iteration(std::integral_constant<int, 3>(), jb);
+      else if (jb <= 6) iteration(std::integral_constant<int, 2>(), jb);
+      else iteration(std::integral_constant<int, 1>(), jb);
+      if (jb + 1 < LEAF / SB) {
+        if (jb == 0) {  // the helpers' part of the LDS image (every column right of block 0)
+          while (sync_w[2] < 3) __builtin_amdgcn_s_sleep(1);
+          wave_lds_fence();
+        }
+        update_diag_tile(jb);
+        wave_lds_fence();
+        LEAF_STAMP(3);
+        if (jb <= 5) {
+          while (sync_w[1] < 3 * (jb + 1)) {}
+          wave_lds_fence();
+        }
+        LEAF_STAMP(4);
+      }
+    }
+    wave_lds_fence();  // the last block's own rows (written behind its flag)
+    if (lane == 0) lds_store(sync_w + 0, LEAF / SB + 1);
+  } else {
+    // ---------------------------------------------------------------- the helpers
+    const int t = tid - 64;
+    {  // the LDS image right of column block 0: row block b holds 16 rows x 8 b pieces of 16 bytes there
+      double2_t v[21];  // sum over row blocks of ceil(128 b / 192)
+      int u = 0;
+#pragma unroll
+      for (int bb = 1; bb < 8; ++bb) {
+        const int per = 8 * bb, cnt = 16 * per;
+#pragma unroll
+        for (int idx0 = 0; idx0 < cnt; idx0 += 192) {
+          const int idx = idx0 + t;
+          if (idx < cnt) v[u] = *reinterpret_cast<const double2_t*>(Ablk + (long)(16 * bb + idx / per) * lda + 16 + 2 * (idx % per));
+          ++u;
+        }
+      }
+      u = 0;
+#pragma unroll
+      for (int bb = 1; bb < 8; ++bb) {
+        const int per = 8 * bb, cnt = 16 * per;
+#pragma unroll
+        for (int idx0 = 0; idx0 < cnt; idx0 += 192) {
+          const int idx = idx0 + t;
+          if (idx < cnt) *reinterpret_cast<double2_t*>(S + soff(16 * bb + idx / per) + 16 + 2 * (idx % per)) = v[u];
+          ++u;
+        }
+      }
+      wave_lds_fence();
+      if (lane == 0) lds_add(sync_a + 2, 1);
+      while (sync_w[2] < 3) __builtin_amdgcn_s_sleep(1);
+      wave_lds_fence();
+    }
+    LEAF_STAMP1(8);
+    // Register-resident trailing tiles (see namespace lt).  Per phase a wave reads one operand set (4 doubles per lane) per
+    // block row it touches -- X~ rows: as they are the MFMA B operand of the tiles in that block column, times -1 / d_k
+    // the A operand of the tiles in that block row -- and issues its tiles' MFMAs interleaved.
+    double4_t tacc[9];
+    auto trailing = [&](auto JBc, auto Wc, auto PHc) {
+      constexpr int JB = decltype(JBc)::value, W = decltype(Wc)::value, PH = decltype(PHc)::value;
+      double opa[8][4], opb[8][4], nr[4];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) nr[s4] = nrv[(JB & 1) * SB + 4 * s4 + kq];
+      lt::static_for<1, 8>([&](auto Bc) {
+        constexpr int B = decltype(Bc)::value;
+        if constexpr (lt::needs_a(W, JB, B, PH) || lt::needs_b(W, JB, B, PH)) {
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) opb[B][s4] = S[soff(16 * B + nn) + 16 * JB + 4 * s4 + kq];
+        }
+        if constexpr (lt::needs_a(W, JB, B, PH)) {
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) opa[B][s4] = opb[B][s4] * nr[s4];
+        }
+      });
+      if constexpr (PH == 0) {
+        // the tiles wave 0 waits for: two accumulator chains of two MFMAs per tile, results to the LDS image
+        double4_t t2[9];
+        lt::static_for<0, 9>([&](auto Sc) {
+          constexpr int Sl = decltype(Sc)::value, I = 3 * Sl + W;
+          if constexpr (lt::sel(I, JB, PH)) t2[Sl] = (double4_t){0.0, 0.0, 0.0, 0.0};
+        });
+#pragma unroll
+        for (int s4 = 0; s4 < 2; ++s4)
+          lt::static_for<0, 9>([&](auto Sc) {
+            constexpr int Sl = decltype(Sc)::value, I = 3 * Sl + W;
+            if constexpr (lt::sel(I, JB, PH)) {
+              tacc[Sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(opa[lt::TR[I]][s4], opb[lt::TC[I]][s4], tacc[Sl], 0, 0, 0);
+              t2[Sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(opa[lt::TR[I]][s4 + 2], opb[lt::TC[I]][s4 + 2], t2[Sl], 0, 0, 0);
+            }
+          });
+        lt::static_for<0, 9>([&](auto Sc) {
+          constexpr int Sl = decltype(Sc)::value, I = 3 * Sl + W;
+          if constexpr (lt::sel(I, JB, PH)) put(tacc[Sl] + t2[Sl], lt::TR[I], lt::TC[I]);
+        });
+      } else {
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+          lt::static_for<0, 9>([&](auto Sc) {
+            constexpr int Sl = decltype(Sc)::value, I = 3 * Sl + W;
+            if constexpr (lt::sel(I, JB, PH))
+              tacc[Sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(opa[lt::TR[I]][s4], opb[lt::TC[I]][s4], tacc[Sl], 0, 0, 0);
+          });
+      }
+    };
+    auto load_tiles = [&](auto Wc) {
+      constexpr int W = decltype(Wc)::value;
       lt::static_for<0, 9>([&](auto Sc) {
         constexpr int I = 3 * decltype(Sc)::value + W;
-        if constexpr (lt::live(I, JB))
-          tacc[decltype(Sc)::value] = __builtin_amdgcn_mfma_f64_16x16x4f64(-op[lt::TR[I]][s4], op[lt::TC[I]][s4], tacc[decltype(Sc)::value], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tacc[decltype(Sc)::value][r] = S[soff(16 * lt::TR[I] + kq + 4 * r) + 16 * lt::TC[I] + nn];
       });
-    lt::static_for<0, 9>([&](auto Sc) {
-      constexpr int I = 3 * decltype(Sc)::value + W;
-      if constexpr (lt::last(I, JB)) put(tacc[decltype(Sc)::value], lt::TR[I], lt::TC[I]);
-    });
-  };
-  auto trailing_all = [&](auto Wc, int jb) {
-    switch (jb) {
-      case 0: trailing(std::integral_constant<int, 0>(), Wc); break;
-      case 1: trailing(std::integral_constant<int, 1>(), Wc); break;
-      case 2: trailing(std::integral_constant<int, 2>(), Wc); break;
-      case 3: trailing(std::integral_constant<int, 3>(), Wc); break;
-      case 4: trailing(std::integral_constant<int, 4>(), Wc); break;
-      case 5: trailing(std::integral_constant<int, 5>(), Wc); break;
-      default: break;
-    }
-  };
-  auto load_tiles = [&](auto Wc) {
-    constexpr int W = decltype(Wc)::value;
-    lt::static_for<0, 9>([&](auto Sc) {
-      constexpr int I = 3 * decltype(Sc)::value + W;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) tacc[decltype(Sc)::value][r] = S[soff(16 * lt::TR[I] + kq + 4 * r) + 16 * lt::TC[I] + nn];
-    });
-  };
-  // Per 16-column block jb, after the diagonal sub-block jb has been factored:
-  //   wave 0     : solves the 16 rows of the NEXT diagonal block, publishes them, updates the next diagonal
-  //                tile and factors it (the serial chain of the leaf);
-  //   waves 1..3 : solve the remaining rows, meet each other and wave 0's rows through two LDS words, apply
-  //                the rank-16 MFMA update to every other trailing tile and stream column block jb out.
-  // Two loops, one per wave role, with the same number of workgroup barriers (s_barrier counts waves, not code
-  // locations): the register-resident tiles of waves 1..3 and the solve / factor state of wave 0 then never share a
-  // live range (in one loop body the kernel needed 256 VGPRs + 204 AGPRs of spill space).
-  if (wave == 0) {
-    for (int jb = 0; jb < LEAF / SB; ++jb) {
-      const int j0 = jb * SB;
-      if (jb + 1 < LEAF / SB) {
-        {  // the 16 rows of the next diagonal block, four lanes per row
-          const int g = lane & 3;
-          double* row = S + soff(j0 + SB + (lane >> 2)) + j0;
-          double x[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) x[i] = row[4 * i + g];
-          const double* LdT = LdT2 + (jb & 1) * SB * SB;
-          double lt[16][4], inv[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) inv[i] = invd[j0 + 4 * i + g];
-#pragma unroll
-          for (int k = 0; k < 15; ++k)
-#pragma unroll
-            for (int i = k >> 2; i < 4; ++i) lt[k][i] = LdT[k * SB + 4 * i + g];
-          __builtin_amdgcn_sched_barrier(0);
-          QuadSolve<0>::run(x, lt, inv, g);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) row[4 * i + g] = x[i];
-        }
-        wave_lds_fence();
-        if (lane == 0) sync_w[0] = jb + 1;
-        LEAF_STAMP(2);
-        update_tile(j0, j0 + SB, j0 + SB);
-        wave_lds_fence();
-        LEAF_STAMP(6);
-        factor_diag(jb + 1);
-        LEAF_STAMP(7);
+    };
+    // Column block cb is final for rows >= 16 cb once wave 0 has published it and nobody reads its unnormalised form any
+    // more: L = X~ D^-1/2 goes back to the LDS image (the inverse phase reads it) and out to memory, 8 pieces of 16 B per
+    // row.  A thread's pieces all lie in ONE column pair (192 is a multiple of 8): two reciprocal square roots per thread.
+    auto stream_out = [&](int cb) {  // at most 6 pieces per thread: all LDS reads first, then the stores (one round trip)
+      const int c0 = cb * SB, npiece = (LEAF - c0) * 8;
+      const int cp = c0 + 2 * (t & 7);
+      const double d0 = pvt[cp], d1 = pvt[cp + 1];
+      const double rs0 = fast_rsqrt(d0), rs1 = fast_rsqrt(d1);
+      if (t < 8) {
+        invd[cp] = rs0;
+        invd[cp + 1] = rs1;
+        int bad = 0;
+        if (!(d1 > 0.0)) bad = cp + 2;
+        if (!(d0 > 0.0)) bad = cp + 1;
+        if (bad != 0) atomicMin(info, col0 + bad);
       }
-      __syncthreads();
-      LEAF_STAMP(3);
-    }
-  } else {
-    if (wave == 1) load_tiles(std::integral_constant<int, 0>());
-    else if (wave == 2) load_tiles(std::integral_constant<int, 1>());
-    else load_tiles(std::integral_constant<int, 2>());
-#pragma unroll  // fully: every copy sees a constant jb, the tile accumulators have plain live ranges (no loop-carried phis
-                // through a switch: that form cost 200 registers of copies and moved the accumulators to AGPRs)
-    for (int jb = 0; jb < LEAF / SB; ++jb) {
-      const int j0 = jb * SB;
-      const int t = tid - 64;
-      const int nrest = LEAF - j0 - 2 * SB;  // rows j0+32 .. 127
-      LEAF_STAMP1(15);  // wait at the previous iteration's barrier
-      if (t < nrest) solve_row(jb, j0 + 2 * SB + t);
-      LEAF_STAMP1(9);   // solve_row
-      // column block cb is final for rows >= 16 cb once iteration cb's rows are solved: 8 pieces of 16 B per row go to
-      // memory.  Block jb - 1 is streamed here, in the time these waves would otherwise spin waiting for wave 0's rows.
-      auto stream_out = [&](int cb) {  // at most 6 pieces per thread: all LDS reads first, then the stores (one round trip)
-        const int c0 = cb * SB, npiece = (LEAF - c0) * 8;
-        double2_t v[6];
-        bool full[6], half[6];
-        double* dst[6];
+      double2_t v[6];
+      bool full[6], half[6];
+      double* dst[6];
+      double* sdst[6];
 #pragma unroll
-        for (int u = 0; u < 6; ++u) {
-          const int it = t + 192 * u;
-          const int r = c0 + (it >> 3), c2 = c0 + 2 * (it & 7);
-          const bool in = it < npiece && c2 <= r;
-          full[u] = in && c2 + 1 <= r;
-          half[u] = in && c2 + 1 > r;
-          dst[u] = Ablk + (long)r * lda + c2;
-          if (in) v[u] = *reinterpret_cast<const double2_t*>(S + soff(r) + c2);
-        }
-#pragma unroll
-        for (int u = 0; u < 6; ++u) {
-          if (full[u]) *reinterpret_cast<double2_t*>(dst[u]) = v[u];
-          else if (half[u]) dst[u][0] = v[u].x;
-        }
-      };
-      if (jb + 1 < LEAF / SB) {
-        wave_lds_fence();
-        if (lane == 0) atomicAdd(const_cast<int*>(sync_w + 1), 1);
-        if (jb > 0) stream_out(jb - 1);
-        while (sync_w[1] < 3 * (jb + 1) || sync_w[0] < jb + 1) __builtin_amdgcn_s_sleep(1);
-        wave_lds_fence();
-      } else {
-        stream_out(jb - 1);
-        stream_out(jb);
+      for (int u = 0; u < 6; ++u) {
+        const int it = t + 192 * u;
+        const int r = c0 + (it >> 3), c2 = c0 + 2 * (it & 7);
+        const bool in = it < npiece && c2 <= r;
+        full[u] = in && c2 + 1 <= r;
+        half[u] = in && c2 + 1 > r;
+        dst[u] = Ablk + (long)r * lda + c2;
+        sdst[u] = S + soff(r) + c2;
+        if (in) v[u] = *reinterpret_cast<const double2_t*>(sdst[u]);
       }
-      LEAF_STAMP1(8);   // arrive, stream-out, spin for wave 0's rows and the other helpers
-      if (wave == 1) trailing_all(std::integral_constant<int, 0>(), jb);
-      else if (wave == 2) trailing_all(std::integral_constant<int, 1>(), jb);
-      else trailing_all(std::integral_constant<int, 2>(), jb);
-      LEAF_STAMP1(10);
-      __syncthreads();
-    }
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        v[u].x *= rs0;
+        v[u].y *= rs1;
+        if (full[u]) {
+          *reinterpret_cast<double2_t*>(dst[u]) = v[u];
+          *reinterpret_cast<double2_t*>(sdst[u]) = v[u];
+        } else if (half[u]) {
+          dst[u][0] = v[u].x;
+          sdst[u][0] = v[u].x;
+        }
+      }
+    };
+    auto helper = [&](auto Wc) {
+      load_tiles(Wc);
+      // fully unrolled: every copy sees a constant jb, the tile accumulators have plain live ranges (no loop-carried phis
+      // through a switch: that form cost 200 registers of copies and moved the accumulators to AGPRs)
+      lt::static_for<0, LEAF / SB>([&](auto JBc) {
+        constexpr int JB = decltype(JBc)::value;
+        while (sync_w[0] < JB + 1) {}
+        wave_lds_fence();
+        LEAF_STAMP1(9);
+        if constexpr (JB <= 5) {
+          trailing(JBc, Wc, std::integral_constant<int, 0>());
+          wave_lds_fence();
+          if (lane == 0) lds_add(sync_a + 1, 1);
+          LEAF_STAMP1(10);
+          trailing(JBc, Wc, std::integral_constant<int, 1>());
+          LEAF_STAMP1(11);
+        }
+        // every helper is through with the unnormalised column block JB - 1 (its lazy phase of iteration JB - 1), and so is
+        // wave 0 (it has published block JB since)
+        if constexpr (JB >= 1) {
+          while (sync_w[3] < 3 * JB) __builtin_amdgcn_s_sleep(1);
+          stream_out(JB - 1);
+        }
+        wave_lds_fence();
+        if (lane == 0) lds_add(sync_a + 3, 1);
+        LEAF_STAMP1(12);
+      });
+      while (sync_w[3] < 3 * (LEAF / SB) || sync_w[0] < LEAF / SB + 1) __builtin_amdgcn_s_sleep(1);
+      stream_out(LEAF / SB - 1);
+    };
+    if (wave == 1) helper(std::integral_constant<int, 0>());
+    else if (wave == 2) helper(std::integral_constant<int, 1>());
+    else helper(std::integral_constant<int, 2>());
   }
-  LEAF_STAMP(4);
+  __syncthreads();
+  LEAF_STAMP(5);
   // ---- M = L^-1 (128x128, lower triangular) in place of L in LDS, streamed to `minv` (row-major, ld 128).
   // (1) the eight 16x16 diagonal blocks by substitution: thread (b, c) solves column c of block b;
   // (2) three levels of block doubling [[L11,0],[L21,L22]]^-1 = [[M11,0],[-M22 L21 M11, M22]] on MFMA: at block size
@@ -558,7 +679,7 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
       __builtin_amdgcn_sched_barrier(0);  // the DPP reads below must not follow the VALU writes of a[] back to back
       DinvStep<0>::run(z, nz, a, iv, c);
     }
-    LEAF_STAMP(11);
+    LEAF_STAMP(16);
     __syncthreads();  // every thread has read its diagonal block before it is overwritten
     if (tid < LEAF) {
 #pragma unroll
@@ -568,7 +689,7 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
       }
     }
     __syncthreads();
-    LEAF_STAMP(12);
+    LEAF_STAMP(17);
   }
 #pragma unroll
   for (int t = 1; t <= 4; t *= 2) {
@@ -595,7 +716,7 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) res[c] = rs2[c][0] + rs2[c][1];
-    LEAF_STAMP(13);
+    LEAF_STAMP(18);
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < 4; ++c)
@@ -620,7 +741,7 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
     }
 #pragma unroll
     for (int a = 0; a < 4; ++a) res[a] = rs2[a][0] + rs2[a][1];
-    LEAF_STAMP(14);
+    LEAF_STAMP(19);
     __syncthreads();
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -633,7 +754,7 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
     }
     __syncthreads();
   }
-  LEAF_STAMP(5);
+  LEAF_STAMP(20);
   // Last tile column of an evaluation: the only rows below are the y^T row block (one non-zero row), so the forward
   // solve of these 128 columns, beta = y M^T, is done here against the inverse that is still in LDS -- the strip launch
   // for that block (6 us of launch and round trips for 16k flops) is skipped.
@@ -801,7 +922,11 @@ __global__ __launch_bounds__(256) void trsm_strip128_kernel(const double* __rest
                          B + (long)blockIdx.y * strideB + (long)blockIdx.z * sB2, ldb, blk);
 }
 
-constexpr size_t LEAF_LDS_BYTES = sizeof(double) * (LEAF_ELEMS + 2 * SB * SB + LEAF + 3);
+// The leaf asks for more LDS than it uses, so that no 72 KB GEMM workgroup fits beside it on a CU: since round 5 its
+// registers (152) would fit beside a bulk wave on a SIMD, and a chain wave that shares the SIMD's fp64 pipe with MFMA-saturated
+// waves runs about half as fast (N = 16384: 25.8 -> 26.2 ms when the two were allowed to share).
+constexpr size_t LEAF_LDS_USED = sizeof(double) * (LEAF_ELEMS + 2 * LEAF + 2 * SB + 4);
+constexpr size_t LEAF_LDS_BYTES = LEAF_LDS_USED > 96 * 1024 ? LEAF_LDS_USED : 96 * 1024;
 
 hipError_t leaf_enable_lds() {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_leaf128_kernel),

@@ -44,35 +44,28 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
 }
 
 #ifdef LEAF_STAMPS
-__device__ unsigned long long g_leaf_stamps[32];
-#define LEAF_STAMP(i)                                                                  \
-  do {                                                                                 \
-    if (threadIdx.x == 0) {                                                            \
-      unsigned long long t_;                                                           \
-      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");        \
-      g_leaf_stamps[i] += t_ - t_prev;                                                 \
-      t_prev = t_;                                                                     \
-    }                                                                                  \
-  } while (0)
-// the same for the first thread of wave 1 (slots 8..15)
-#define LEAF_STAMP1(i)                                                                 \
-  do {                                                                                 \
-    if (threadIdx.x == 64) {                                                           \
-      unsigned long long t_;                                                           \
-      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");        \
-      g_leaf_stamps[i] += t_ - t_prev1;                                                \
-      t_prev1 = t_;                                                                    \
-    }                                                                                  \
+// Dev probe (tools/leaf_timing.hip): ONE time stamp per launch, at the program point the host selects, relative to the
+// wave's start -- s_memtime is a scalar memory round trip (~250 cycles), so a kernel with a stamp at every phase boundary
+// measures mostly its stamps.  Wave 0 sites: 8 jb + k; wave 1 sites: 64 + 8 jb + k.
+__device__ unsigned long long g_leaf_probe_out;
+__device__ int g_leaf_probe_sel;
+#define LEAF_PROBE(code)                                                                    \
+  do {                                                                                      \
+    if (probe_sel == (code) && (threadIdx.x & 63) == 0 && threadIdx.x <= 64) {              \
+      unsigned long long t_;                                                                \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");           \
+      g_leaf_probe_out = t_ - t_start;                                                      \
+    }                                                                                       \
   } while (0)
 #else
-#define LEAF_STAMP(i)
-#define LEAF_STAMP1(i)
+#define LEAF_PROBE(code)
 #endif
 
 // LDS words the waves of the leaf meet through, as LDS instructions: through a generic `volatile int*` the compiler emits
 // FLAT loads / stores with system-scope cache bits and vmcnt waits (round 4's listing), and a workgroup-scope fence also
 // waits for the wave's outstanding GLOBAL stores (the column stream-out).
 typedef __attribute__((address_space(3))) int lds_int_t;
+typedef __attribute__((address_space(3))) double lds_double_t;
 __device__ __forceinline__ int lds_load(volatile lds_int_t* p) { return *p; }
 __device__ __forceinline__ void lds_store(volatile lds_int_t* p, int v) { *p = v; }
 __device__ __forceinline__ void lds_add(lds_int_t* p, int v) {
@@ -314,31 +307,40 @@ __device__ __forceinline__ void static_for(F&& f) {
 //
 // Structure (round 5) per 16-column block jb of the 128x128 leaf:
 //  wave 0 (the chain): holds the diagonal 16x16 block AND every row below it in registers (ch::Step above: two or three
-//      16-column panels per lane), eliminates the 16 columns, writes the unnormalised columns X~ to the LDS image and the
-//      multipliers W = -X~ D^-1 to a side buffer, raises `ready`, applies the rank-16 update  += W X~^T  to the NEXT
-//      diagonal tile on MFMA and waits for the helpers' urgent tiles -- the rest of the next panel.
+//      16-column panels per lane), eliminates the 16 columns, writes the unnormalised columns X~ of the rows below to the
+//      LDS image with the pivots d and -1/d, raises `ready`, applies the rank-16 update  -= (X~ D^-1) X~^T  to the NEXT
+//      diagonal tile on MFMA and waits for the helpers' urgent tiles -- the rest of the next panel.  Sixteen otherwise idle
+//      lanes carry the rows of the identity through the same elimination: Y_jb = L~_jb^-T, the block's triangular inverse
+//      up to scalings, for free.
 //  waves 1..3 (helpers): keep the 27 trailing 16x16 tiles in registers (namespace lt), left-looking.  Behind `ready` they
 //      first finish the tiles of the NEXT block column (their last update: results go to the LDS image, `urgent` is
-//      raised), then update the other live tiles while wave 0 already eliminates the next block, then normalise the
-//      PREVIOUS column block (L = X~ D^-1/2, in the LDS image and out to memory).  No workgroup barrier inside the loop:
-//      the sides meet through LDS counters.
+//      raised), then update the other live tiles while wave 0 already eliminates the next block; then, in the time they
+//      used to spin, they form block row jb of M = L^-1 from Y_jb and the rows above (see `inverse`), and normalise column
+//      block jb - 1 on its way out to memory (L = X~ D^-1/2; the LDS image stays unnormalised).
+// No workgroup barrier inside the loop: the sides meet through LDS counters.  The explicit inverse used to be a phase of its
+// own behind the factorisation (8 substitutions + three block-doubling levels, ~6 us of the leaf's 30); what is left behind
+// the last pivot now is one 16x16x16 product per tile of the last block row.
+constexpr int YB_LD = 18;                       // row stride of an identity-row buffer (16 rows at one column: 16 bank pairs)
+constexpr int MT_ELEMS = 256;                   // one 16x16 tile of M^ in MFMA operand order: [r][lane] <-> element [kq + 4 r][n]
+__device__ __forceinline__ constexpr int mt_off(int b, int c) { return (b * (b + 1) / 2 + c) * MT_ELEMS; }
 __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, long lda, double* __restrict__ minv,
                                                     int col0, int* __restrict__ info, double* smem, double* yrow) {
-  double* S = smem;                     // packed lower block-trapezoid, see soff()
-  double* invd = smem + LEAF_ELEMS;     // [128] 1 / L[c][c]
-  double* pvt = invd + LEAF;            // [128] the pivots d_c (L[c][c]^2)
-  double* nrv = pvt + LEAF;             // [2][16] -1 / d_c of the current column block (buffer jb & 1)
-  lds_int_t* sync_a = (lds_int_t*)(nrv + 2 * SB);
+  double* S = smem;                     // packed lower block-trapezoid, see soff(): X~ (unnormalised columns of L)
+  double* pvt = smem + LEAF_ELEMS;      // [128] the pivots d_c (L[c][c]^2)
+  double* nra = pvt + LEAF;             // [128] -1 / d_c
+  double* Ybuf = nra + LEAF;            // [4][16][YB_LD] identity rows of block jb (buffer jb & 3)
+  double* Mh = Ybuf + 4 * SB * YB_LD;   // [36][MT_ELEMS] M^ = D^-1/2 M (block row b, block column c <= b at mt_off(b, c))
+  lds_int_t* sync_a = (lds_int_t*)(Mh + 36 * MT_ELEMS);
   volatile lds_int_t* sync_w = sync_a;  // [0] column blocks published by wave 0, [1] urgent
-  // arrivals of waves 1..3, [2] their load arrivals, [3] their lazy-phase arrivals
+  // arrivals of waves 1..3, [2] their load arrivals, [3] their arrivals with a block row of M^
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: tile coordinates and soff() bases derived
                                                               // from it are computed on the scalar unit (v_mul_lo_u32 is quarter rate)
 #ifdef LEAF_STAMPS
-  unsigned long long t_prev = 0, t_prev1 = 0;
-  if (threadIdx.x == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory");
-  if (threadIdx.x == 64) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev1)::"memory");
+  const int probe_sel = __builtin_amdgcn_readfirstlane(g_leaf_probe_sel);
+  unsigned long long t_start;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_start)::"memory");
 #endif
   typedef double double2_t __attribute__((ext_vector_type(2)));
   if (tid == 64) { sync_w[0] = 0; sync_w[1] = 0; sync_w[2] = 0; sync_w[3] = 0; }
@@ -358,39 +360,44 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
       constexpr int NA = decltype(NAc)::value;
       const int j0 = jb * SB;
       const int r16 = lane & 15;
-      int row[3];
-      bool valid[3];
-      row[0] = j0 + r16;
-      row[1] = j0 + SB + lane;
-      row[2] = j0 + SB + 64 + lane;
-      valid[0] = lane < SB;
-      valid[1] = row[1] < LEAF;
-      valid[2] = row[2] < LEAF;
+      LEAF_PROBE(8 * jb + 0);
+      // panel 0: the diagonal block's row r16 (mirrored); panel i >= 1, lane l: row g = j0 + 16 + 64 (i - 1) + l of the leaf,
+      // or, for 128 <= g < 144, row g - 128 of the identity, or nothing
       double a[NA][16];
-      if (jb == 0) {  // straight from memory: the chain starts one global round trip after the launch
+      lds_double_t* dst[NA];  // (explicit LDS pointers: a pointer chosen between two LDS arrays per lane becomes a FLAT access otherwise)
+      bool writes[NA];
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
-          const double* src = Ablk + (long)(valid[i] ? row[i] : row[0]) * lda;
+      for (int i = 0; i < NA; ++i) {
+        const int g = i == 0 ? j0 + r16 : j0 + SB + 64 * (i - 1) + lane;
+        const bool real = g < LEAF, ident = !real && g < LEAF + SB;
+        writes[i] = i == 0 ? lane < SB : (real || ident);
+        const int off = real ? soff(g) + j0 : (int)(Ybuf - smem) + (jb & 3) * (SB * YB_LD) + (ident ? g - LEAF : 0) * YB_LD;
+        dst[i] = (lds_double_t*)smem + off;
+        // block 0 straight from memory: the chain starts one global round trip after the launch.  Lanes without a row of
+        // the leaf read the block's own row and are overwritten below.
+        if (jb == 0) {
+          const double* src = Ablk + (long)(real ? g : r16) * lda;
 #pragma unroll
           for (int c = 0; c < SB; c += 2) {
             const double2_t v = *reinterpret_cast<const double2_t*>(src + c);
+            a[i][c] = v.x;
+            a[i][c + 1] = v.y;
+          }
+        } else {
+          const lds_double_t* src = (const lds_double_t*)smem + (real ? off : soff(j0 + r16) + j0);
+#pragma unroll
+          for (int c = 0; c < SB; c += 2) {
+            const double2_t v = *reinterpret_cast<const __attribute__((address_space(3))) double2_t*>(src + c);
             a[i][c] = v.x;
             a[i][c + 1] = v.y;
           }
         }
-      } else {
+        if (i == NA - 1) {  // only the last panel can hold identity rows / idle lanes
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
-          const double* src = S + soff(valid[i] ? row[i] : row[0]) + j0;
-#pragma unroll
-          for (int c = 0; c < SB; c += 2) {
-            const double2_t v = *reinterpret_cast<const double2_t*>(src + c);
-            a[i][c] = v.x;
-            a[i][c + 1] = v.y;
-          }
+          for (int c = 0; c < SB; ++c) a[i][c] = real ? a[i][c] : ((ident && g - LEAF == c) ? 1.0 : 0.0);
         }
       }
-      LEAF_STAMP(0);
+      LEAF_PROBE(8 * jb + 1);
       __builtin_amdgcn_sched_barrier(0);
       {
         double w0[NA];
@@ -398,7 +405,7 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
         for (int i = 0; i < NA; ++i) w0[i] = 0.0;
         ch::Step<0, NA>::run(a, ch::mov_bc_padded<0>(a[0][0]), w0);
       }
-      LEAF_STAMP(24 + jb);
+      LEAF_PROBE(8 * jb + 2);
       // lane c keeps the pivot d_c = a[0][c] (a run-time register index would put the panels into scratch) and -1 / d_c
       double my_p = a[0][0];
 #pragma unroll
@@ -410,49 +417,66 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
         const double nq = __builtin_fma(-e0, e0, -e0);
         my_nr = __builtin_fma(y0, nq, -y0);
       }
-      // X~ of the rows below the block, the pivots and their reciprocals first: the updates wait for them; the block's own
-      // rows are read by nobody before the normalisation
+      // X~ of the rows below the block (and the identity rows), the pivots and their reciprocals first: the updates wait for
+      // them; the block's own rows are read by nobody before the normalisation
 #pragma unroll
       for (int i = 1; i < NA; ++i) {
-        if (valid[i]) {
-          double* dst = S + soff(row[i]) + j0;
+        if (writes[i]) {
 #pragma unroll
           for (int c = 0; c < SB; c += 2) {
             double2_t v;
             v.x = a[i][c];
             v.y = a[i][c + 1];
-            *reinterpret_cast<double2_t*>(dst + c) = v;
+            *reinterpret_cast<__attribute__((address_space(3))) double2_t*>(dst[i] + c) = v;
           }
         }
       }
       pvt[j0 + r16] = my_p;  // (the four 16-lane rows write the same values)
-      nrv[(jb & 1) * SB + r16] = my_nr;
+      nra[j0 + r16] = my_nr;
       wave_lds_fence();
       if (lane == 0) lds_store(sync_w + 0, jb + 1);
-      if (lane < SB) {
-        double* dst = S + soff(row[0]) + j0;
+      if (writes[0]) {
 #pragma unroll
         for (int c = 0; c < SB; c += 2) {
           double2_t v;
           v.x = a[0][c];
           v.y = a[0][c + 1];
-          *reinterpret_cast<double2_t*>(dst + c) = v;
+          *reinterpret_cast<__attribute__((address_space(3))) double2_t*>(dst[0] + c) = v;
         }
       }
-      LEAF_STAMP(2);
+      if constexpr (NA == 2) {
+        if (jb == LEAF / SB - 1) {
+          // The last block: its L (lane r holds row r of X~) and its tile of M (lane i holds row i of Y = column i of the
+          // block's inverse up to scalings) go to memory straight from the registers, while the helpers form the rest of the
+          // last block row of M:  L[r][c] = X~[r][c] d_c^-1/2,  M[J][i] = d_J^-1/2 Y[i][J]
+          const double rs = fast_rsqrt(my_p);
+          const unsigned long long neg = __ballot(!(my_p > 0.0)) & 0xffffull;
+          if (neg != 0 && lane == 0) atomicMin(info, col0 + j0 + __ffsll((long long)neg));
+#pragma unroll
+          for (int c = 0; c < SB; ++c) {
+            const double rc = bcast_lane(rs, c);
+            if (lane < SB) {
+              if (c <= r16) Ablk[(long)(j0 + r16) * lda + j0 + c] = a[0][c] * rc;
+              const double m = a[1][c] * rc;  // M[j0 + c][j0 + lane]
+              minv[(long)(j0 + c) * LEAF + j0 + lane] = m;
+              Mh[mt_off(LEAF / SB - 1, LEAF / SB - 1) + 64 * (c >> 2) + 16 * (c & 3) + lane] = m;
+            }
+          }
+        }
+      }
+      LEAF_PROBE(8 * jb + 3);
     };
     // rank-16 update of the next diagonal tile: S[r0.., r0..] -= (X~ D^-1) X~^T with the rows r0.. of columns j0..j0+15;
     // four independent accumulators (a dependent fp64 MFMA follows its predecessor after ~250 cycles)
     auto update_diag_tile = [&](int jb) {
       const int j0 = jb * SB, r0 = j0 + SB;
-      const double* nr = nrv + (jb & 1) * SB;
       const double4_t z4 = {0.0, 0.0, 0.0, 0.0};
       double4_t acc, p1 = z4, p2 = z4, p3 = z4;
       double av[4], bv[4];
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
         bv[s4] = S[soff(r0 + nn) + j0 + 4 * s4 + kq];
-        av[s4] = bv[s4] * nr[4 * s4 + kq];
+        av[s4] = bv[s4] * nra[j0 + 4 * s4 + kq];
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[r] = S[soff(r0 + kq + 4 * r) + r0 + nn];
@@ -465,9 +489,9 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
       for (int r = 0; r < 4; ++r) S[soff(r0 + kq + 4 * r) + r0 + nn] = acc[r];
     };
     for (int jb = 0; jb < LEAF / SB; ++jb) {
-      if (jb <= 2) iteration(std::integral_constant<int, 3>(), jb);
-      else if (jb <= 6) iteration(std::integral_constant<int, 2>(), jb);
-      else iteration(std::integral_constant<int, 1>(), jb);
+      // (the identity rows ride in the last panel's idle lanes; blocks 3 and 7 have none and take a panel for them)
+      if (jb <= 3) iteration(std::integral_constant<int, 3>(), jb);
+      else iteration(std::integral_constant<int, 2>(), jb);
       if (jb + 1 < LEAF / SB) {
         if (jb == 0) {  // the helpers' part of the LDS image (every column right of block 0)
           while (sync_w[2] < 3) __builtin_amdgcn_s_sleep(1);
@@ -475,16 +499,14 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
         }
         update_diag_tile(jb);
         wave_lds_fence();
-        LEAF_STAMP(3);
+        LEAF_PROBE(8 * jb + 4);
         if (jb <= 5) {
           while (sync_w[1] < 3 * (jb + 1)) {}
           wave_lds_fence();
         }
-        LEAF_STAMP(4);
+        LEAF_PROBE(8 * jb + 5);
       }
     }
-    wave_lds_fence();  // the last block's own rows (written behind its flag)
-    if (lane == 0) lds_store(sync_w + 0, LEAF / SB + 1);
   } else {
     // ---------------------------------------------------------------- the helpers
     const int t = tid - 64;
@@ -517,7 +539,7 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
       while (sync_w[2] < 3) __builtin_amdgcn_s_sleep(1);
       wave_lds_fence();
     }
-    LEAF_STAMP1(8);
+    LEAF_PROBE(62);
     // Register-resident trailing tiles (see namespace lt).  Per phase a wave reads one operand set (4 doubles per lane) per
     // block row it touches -- X~ rows: as they are the MFMA B operand of the tiles in that block column, times -1 / d_k
     // the A operand of the tiles in that block row -- and issues its tiles' MFMAs interleaved.
@@ -526,7 +548,7 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
       constexpr int JB = decltype(JBc)::value, W = decltype(Wc)::value, PH = decltype(PHc)::value;
       double opa[8][4], opb[8][4], nr[4];
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) nr[s4] = nrv[(JB & 1) * SB + 4 * s4 + kq];
+      for (int s4 = 0; s4 < 4; ++s4) nr[s4] = nra[16 * JB + 4 * s4 + kq];
       lt::static_for<1, 8>([&](auto Bc) {
         constexpr int B = decltype(Bc)::value;
         if constexpr (lt::needs_a(W, JB, B, PH) || lt::needs_b(W, JB, B, PH)) {
@@ -576,17 +598,15 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
         for (int r = 0; r < 4; ++r) tacc[decltype(Sc)::value][r] = S[soff(16 * lt::TR[I] + kq + 4 * r) + 16 * lt::TC[I] + nn];
       });
     };
-    // Column block cb is final for rows >= 16 cb once wave 0 has published it and nobody reads its unnormalised form any
-    // more: L = X~ D^-1/2 goes back to the LDS image (the inverse phase reads it) and out to memory, 8 pieces of 16 B per
-    // row.  A thread's pieces all lie in ONE column pair (192 is a multiple of 8): two reciprocal square roots per thread.
+    // Column block cb is final for rows >= 16 cb once wave 0 has published it: L = X~ D^-1/2 goes out to memory, 8 pieces
+    // of 16 B per row (the LDS image keeps X~).  A thread's pieces all lie in ONE column pair (192 is a multiple of 8): two
+    // reciprocal square roots per thread.
     auto stream_out = [&](int cb) {  // at most 6 pieces per thread: all LDS reads first, then the stores (one round trip)
       const int c0 = cb * SB, npiece = (LEAF - c0) * 8;
       const int cp = c0 + 2 * (t & 7);
       const double d0 = pvt[cp], d1 = pvt[cp + 1];
       const double rs0 = fast_rsqrt(d0), rs1 = fast_rsqrt(d1);
       if (t < 8) {
-        invd[cp] = rs0;
-        invd[cp + 1] = rs1;
         int bad = 0;
         if (!(d1 > 0.0)) bad = cp + 2;
         if (!(d0 > 0.0)) bad = cp + 1;
@@ -595,7 +615,6 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
       double2_t v[6];
       bool full[6], half[6];
       double* dst[6];
-      double* sdst[6];
 #pragma unroll
       for (int u = 0; u < 6; ++u) {
         const int it = t + 192 * u;
@@ -604,169 +623,172 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
         full[u] = in && c2 + 1 <= r;
         half[u] = in && c2 + 1 > r;
         dst[u] = Ablk + (long)r * lda + c2;
-        sdst[u] = S + soff(r) + c2;
-        if (in) v[u] = *reinterpret_cast<const double2_t*>(sdst[u]);
+        if (in) v[u] = *reinterpret_cast<const double2_t*>(S + soff(r) + c2);
       }
 #pragma unroll
       for (int u = 0; u < 6; ++u) {
         v[u].x *= rs0;
         v[u].y *= rs1;
-        if (full[u]) {
-          *reinterpret_cast<double2_t*>(dst[u]) = v[u];
-          *reinterpret_cast<double2_t*>(sdst[u]) = v[u];
-        } else if (half[u]) {
-          dst[u][0] = v[u].x;
-          sdst[u][0] = v[u].x;
-        }
+        if (full[u]) *reinterpret_cast<double2_t*>(dst[u]) = v[u];
+        else if (half[u]) dst[u][0] = v[u].x;
       }
+    };
+    // ---- M = L^-1 (row-major 128 x 128 in `minv`), block row by block row, in the helpers' idle time.
+    // With L = X~ D^-1/2 (X~ the unnormalised columns, D = diag(d)) and Y_b = the identity rows wave 0 carried through block b
+    // (Y_b[i][J] = (L~_bb^-T)[i][J] with L~_bb = X~_bb D_b^-1 unit lower triangular), M^ = D^-1/2 M obeys
+    //   M^[b][b] = D_b^-1 Y_b^T,     M^[b][c] = -D_b^-1 Y_b^T  T[b][c],   T[b][c] = sum_{k = c}^{b - 1} X~[b][k] M^[k][c]   (c < b)
+    // -- products of tiles that are in the LDS image unnormalised, so a block row never waits for a reciprocal square root;
+    // M = D^1/2 M^ is scaled on its way to memory.  Wave w takes the block columns c = w, w + 3, w + 6.  T[b][.] is formed
+    // one iteration ahead (everything but Y_b is there), so behind the last pivot only the 16x16x16 products with Y_7 remain.
+    // An MFMA result (lane: [kq + 4 r][n]) IS the B operand of the next product (lane: [4 s + kq][n]): T goes from the
+    // accumulators of the first product into the second, and M^ tiles are stored in that order ([r][lane]: no bank conflicts).
+    double4_t tsum[3], tbulk[3];  // T[b][c] of this wave's columns for the next block row (complete) / the one after (terms k <= b - 2)
+    // acc[q] += sum_{k = KLO}^{KHI - 1} X~[B][k] M^[k][c] for this wave's columns c = W + 3 q <= k: k-outer, the columns
+    // interleaved, four partial accumulators per tile -- up to twelve independent MFMA chains (a dependent fp64 MFMA follows
+    // its predecessor after ~250 cycles) and one read of the X~[B][k] operand per k
+    auto inv_acc = [&](auto Bc, auto Wc, auto KLOc, auto KHIc, double4_t (&acc)[3]) {
+      constexpr int B = decltype(Bc)::value, W = decltype(Wc)::value, KLO = decltype(KLOc)::value, KHI = decltype(KHIc)::value;
+      if constexpr (W < KHI && KLO < KHI) {
+        const double4_t z4 = {0.0, 0.0, 0.0, 0.0};
+        double4_t p[3][4];
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) p[q][s4] = z4;
+        lt::static_for<(KLO > W ? KLO : W), KHI>([&](auto Kc) {
+          constexpr int K = decltype(Kc)::value;
+          double xa[4];
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) xa[s4] = S[soff(16 * B + nn) + 16 * K + 4 * s4 + kq];
+          lt::static_for<0, 3>([&](auto Qc) {
+            constexpr int Q = decltype(Qc)::value, C = W + 3 * Q;
+            if constexpr (C <= K) {
+#pragma unroll
+              for (int s4 = 0; s4 < 4; ++s4)
+                p[Q][s4] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[s4], Mh[mt_off(K, C) + 64 * s4 + lane], p[Q][s4], 0, 0, 0);
+            }
+          });
+        });
+        lt::static_for<0, 3>([&](auto Qc) {
+          constexpr int Q = decltype(Qc)::value, C = W + 3 * Q;
+          if constexpr (C < KHI) acc[Q] += (p[Q][0] + p[Q][1]) + (p[Q][2] + p[Q][3]);
+        });
+      }
+    };
+    auto inv_final = [&](auto Bc, auto Wc) {  // block row B of M^ and of M for this wave's columns c < B (and the diagonal tile)
+      constexpr int B = decltype(Bc)::value, W = decltype(Wc)::value;
+      constexpr bool LAST = B == LEAF / SB - 1;  // nothing reads M^ of the last block row: M itself, and wave 0 takes its diagonal tile
+      if constexpr (W < B || (W == B % 3 && !LAST)) {
+        const double* Y = Ybuf + (B & 3) * (SB * YB_LD);
+        // A operand of the second product: (-D_b^-1 Y_b^T)[n][4 s + kq] = nra[16 B + n] * Y[4 s + kq][n]; for the last block row
+        // the scaling of M's rows by sqrt(d) is folded in: -d^-1/2 instead of -1 / d (one reciprocal square root per lane)
+        const double nrn = LAST ? -fast_rsqrt(pvt[16 * B + nn]) : nra[16 * B + nn];
+        double ya[4], sq[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) ya[s4] = nrn * Y[(4 * s4 + kq) * YB_LD + nn];
+        if constexpr (!LAST) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {  // rows kq + 4 r of block row B are scaled by sqrt(d) on their way out
+            const double d = pvt[16 * B + kq + 4 * r];
+            sq[r] = d * fast_rsqrt(d);
+          }
+        }
+        lt::static_for<0, 3>([&](auto Qc) {
+          constexpr int Q = decltype(Qc)::value, C = W + 3 * Q;
+          if constexpr (C < B) {
+            const double4_t z4 = {0.0, 0.0, 0.0, 0.0};
+            double4_t m0 = z4, m1 = z4;
+            m0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[0], tsum[Q][0], m0, 0, 0, 0);
+            m1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[1], tsum[Q][1], m1, 0, 0, 0);
+            m0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[2], tsum[Q][2], m0, 0, 0, 0);
+            m1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[3], tsum[Q][3], m1, 0, 0, 0);
+            m0 += m1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              Mh[mt_off(B, C) + 64 * r + lane] = m0[r];
+              minv[(long)(16 * B + kq + 4 * r) * LEAF + 16 * C + nn] = LAST ? m0[r] : m0[r] * sq[r];
+            }
+          } else if constexpr (C == B && !LAST) {  // the diagonal tile: D_b^-1 Y_b^T, element [J][i] = -nra[J] Y[i][J]
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int J = kq + 4 * r;
+              const double v = -nra[16 * B + J] * Y[nn * YB_LD + J];
+              Mh[mt_off(B, B) + 64 * r + lane] = v;
+              minv[(long)(16 * B + J) * LEAF + 16 * B + nn] = v * sq[r];
+            }
+          }
+        });
+      }
+      wave_lds_fence();
+      if (lane == 0) lds_add(sync_a + 3, 1);
+    };
+    // T of the next block row gets its last term (k = JB: block row JB of M^ is the newest, every helper has to be through
+    // with it), T of the one after its terms k <= JB
+    auto inv_t = [&](auto JBc, auto Wc) {
+      constexpr int JB = decltype(JBc)::value, NB = LEAF / SB;
+      const double4_t z4 = {0.0, 0.0, 0.0, 0.0};
+      if constexpr (JB + 1 < NB) {
+        while (sync_w[3] < 3 * (JB + 1)) __builtin_amdgcn_s_sleep(1);
+        wave_lds_fence();
+#pragma unroll
+        for (int q = 0; q < 3; ++q) tsum[q] = tbulk[q];
+        inv_acc(std::integral_constant<int, JB + 1>(), Wc, JBc, std::integral_constant<int, JB + 1>(), tsum);
+      }
+#pragma unroll
+      for (int q = 0; q < 3; ++q) tbulk[q] = z4;
+      if constexpr (JB + 2 < NB)
+        inv_acc(std::integral_constant<int, JB + 2>(), Wc, std::integral_constant<int, 0>(), std::integral_constant<int, JB + 1>(), tbulk);
     };
     auto helper = [&](auto Wc) {
       load_tiles(Wc);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) tbulk[q] = (double4_t){0.0, 0.0, 0.0, 0.0};
       // fully unrolled: every copy sees a constant jb, the tile accumulators have plain live ranges (no loop-carried phis
       // through a switch: that form cost 200 registers of copies and moved the accumulators to AGPRs)
       lt::static_for<0, LEAF / SB>([&](auto JBc) {
         constexpr int JB = decltype(JBc)::value;
         while (sync_w[0] < JB + 1) {}
         wave_lds_fence();
-        LEAF_STAMP1(9);
+        LEAF_PROBE(64 + 8 * JB + 0);
         if constexpr (JB <= 5) {
           trailing(JBc, Wc, std::integral_constant<int, 0>());
           wave_lds_fence();
           if (lane == 0) lds_add(sync_a + 1, 1);
-          LEAF_STAMP1(10);
+          LEAF_PROBE(64 + 8 * JB + 1);
           trailing(JBc, Wc, std::integral_constant<int, 1>());
-          LEAF_STAMP1(11);
+          LEAF_PROBE(64 + 8 * JB + 2);
         }
-        // every helper is through with the unnormalised column block JB - 1 (its lazy phase of iteration JB - 1), and so is
-        // wave 0 (it has published block JB since)
-        if constexpr (JB >= 1) {
-          while (sync_w[3] < 3 * JB) __builtin_amdgcn_s_sleep(1);
-          stream_out(JB - 1);
-        }
-        wave_lds_fence();
-        if (lane == 0) lds_add(sync_a + 3, 1);
-        LEAF_STAMP1(12);
+        inv_final(JBc, Wc);
+        LEAF_PROBE(64 + 8 * JB + 3);
+        if constexpr (JB >= 1) stream_out(JB - 1);
+        LEAF_PROBE(64 + 8 * JB + 4);
+        inv_t(JBc, Wc);
+        LEAF_PROBE(64 + 8 * JB + 5);
       });
-      while (sync_w[3] < 3 * (LEAF / SB) || sync_w[0] < LEAF / SB + 1) __builtin_amdgcn_s_sleep(1);
-      stream_out(LEAF / SB - 1);
+      // (wave 0 writes the last diagonal block of L and of M from its registers)
     };
     if (wave == 1) helper(std::integral_constant<int, 0>());
     else if (wave == 2) helper(std::integral_constant<int, 1>());
     else helper(std::integral_constant<int, 2>());
   }
-  __syncthreads();
-  LEAF_STAMP(5);
-  // ---- M = L^-1 (128x128, lower triangular) in place of L in LDS, streamed to `minv` (row-major, ld 128).
-  // (1) the eight 16x16 diagonal blocks by substitution: thread (b, c) solves column c of block b;
-  // (2) three levels of block doubling [[L11,0],[L21,L22]]^-1 = [[M11,0],[-M22 L21 M11, M22]] on MFMA: at block size
-  //     t = 1, 2, 4 tiles stage A forms T = L21 M11 (wave = tile row), stage B forms -M22 T (wave = tile column);
-  //     28 tile products per wave, the wave's up to four tiles of a stage accumulate interleaved (a dependent fp64 MFMA
-  //     chain issues at a quarter of the independent rate), results replace L21 in LDS between barriers.
-  // (An interleaved variant -- one block row of M per iteration of the loop above, in the shadow of wave 0's chain --
-  // was built and measured in round 2: 69 us instead of 36: the 16x16 inverse by substitution (4.2k cycles per block on
-  // one wave) and five LDS-word syncs per iteration outweigh the 4 us this block costs at the end.)
-  {
-    double z[SB], nz[SB], a[SB], iv[SB];
-    const int b = tid >> 4, c = tid & 15, j0 = b * SB;
-    if (tid < LEAF) {  // waves 0 and 1: a 16-lane DPP row = one diagonal block, lane c holds row c of L_bb
-      const double* lrow = S + soff(j0 + c) + j0;
-#pragma unroll
-      for (int k = 0; k < SB; ++k) {
-        a[k] = lrow[k];
-        iv[k] = invd[j0 + k];
-        nz[k] = 0.0;
-      }
-      __builtin_amdgcn_sched_barrier(0);  // the DPP reads below must not follow the VALU writes of a[] back to back
-      DinvStep<0>::run(z, nz, a, iv, c);
-    }
-    LEAF_STAMP(16);
-    __syncthreads();  // every thread has read its diagonal block before it is overwritten
-    if (tid < LEAF) {
-#pragma unroll
-      for (int r = 0; r < SB; ++r) {
-        S[soff(j0 + r) + j0 + c] = z[r];  // zeros above the diagonal: the tiles are read whole as MFMA operands
-        minv[(long)(j0 + r) * LEAF + j0 + c] = z[r];
-      }
-    }
-    __syncthreads();
-    LEAF_STAMP(17);
-  }
-#pragma unroll
-  for (int t = 1; t <= 4; t *= 2) {
-    const int node = wave / t, p0 = node * 2 * t, idx = wave % t;
-    double4_t res[4], rs2[4][2];  // two partial accumulators per tile (MFMA steps s4 even / odd): chains half as long
-#pragma unroll
-    for (int c = 0; c < 4; ++c) rs2[c][0] = rs2[c][1] = (double4_t){0.0, 0.0, 0.0, 0.0};
-    // stage A: T[a][c] = sum_{k >= c} L[p0+t+a][p0+k] M[p0+k][p0+c], this wave owns tile row a = idx; the k-th
-    // products of its t tiles are issued together (independent accumulators)
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (k < t) {
-        double av[4];
-        const double* ap = S + soff(16 * (p0 + t + idx) + nn) + 16 * (p0 + k) + kq;
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) av[s4] = ap[4 * s4];
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-          for (int c = 0; c < 4; ++c)
-            if (c <= k && c < t)
-              rs2[c][s4 & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s4], S[soff(16 * (p0 + k) + 4 * s4 + kq) + 16 * (p0 + c) + nn], rs2[c][s4 & 1], 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) res[c] = rs2[c][0] + rs2[c][1];
-    LEAF_STAMP(18);
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-      if (c < t) put(res[c], p0 + t + idx, p0 + c);
-    __syncthreads();
-    // stage B: M21[a][c] = - sum_{k <= a} M[p0+t+a][p0+t+k] T[k][c], this wave owns tile column c = idx
-#pragma unroll
-    for (int a = 0; a < 4; ++a) rs2[a][0] = rs2[a][1] = (double4_t){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (k < t) {
-        double bv[4];
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) bv[s4] = S[soff(16 * (p0 + t + k) + 4 * s4 + kq) + 16 * (p0 + idx) + nn];
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-          for (int a = 0; a < 4; ++a)
-            if (a >= k && a < t)
-              rs2[a][s4 & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(S[soff(16 * (p0 + t + a) + nn) + 16 * (p0 + t + k) + 4 * s4 + kq], bv[s4], rs2[a][s4 & 1], 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int a = 0; a < 4; ++a) res[a] = rs2[a][0] + rs2[a][1];
-    LEAF_STAMP(19);
-    __syncthreads();
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      if (a < t) {
-        const double4_t v = -res[a];
-        put(v, p0 + t + a, p0 + idx);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) minv[(long)(16 * (p0 + t + a) + kq + 4 * r) * LEAF + 16 * (p0 + idx) + nn] = v[r];
-      }
-    }
-    __syncthreads();
-  }
-  LEAF_STAMP(20);
+  LEAF_PROBE(63);
   // Last tile column of an evaluation: the only rows below are the y^T row block (one non-zero row), so the forward
   // solve of these 128 columns, beta = y M^T, is done here against the inverse that is still in LDS -- the strip launch
   // for that block (6 us of launch and round trips for 16k flops) is skipped.
   if (yrow != nullptr) {
-    if (tid < LEAF) invd[tid] = yrow[tid];
+    __syncthreads();
+    double* ys = Ybuf;  // scratch
+    if (tid < LEAF) ys[tid] = yrow[tid];
     __syncthreads();
     const int c = tid >> 1, half = tid & 1;
-    const double* mrow = S + soff(c);
+    // M[c][k] = sqrt(d_c) M^[c][k]; M^ element [i][j] of tile (b, cb) sits at mt_off(b, cb) + 64 (i >> 2) + 16 (i & 3) + j
+    const int b = c >> 4, i = c & 15;
+    const double* mrow = Mh + mt_off(b, 0) + 64 * (i >> 2) + 16 * (i & 3);
     double acc = 0.0;
-    for (int k = half; k <= c; k += 2) acc = __builtin_fma(mrow[k], invd[k], acc);
+    for (int k = half; k <= c; k += 2) acc = __builtin_fma(mrow[(k >> 4) * MT_ELEMS + (k & 15)], ys[k], acc);
     acc += __shfl_xor(acc, 1);
-    if (half == 0) yrow[c] = acc;
+    const double d = pvt[c];
+    if (half == 0) yrow[c] = b == LEAF / SB - 1 ? acc : acc * (d * fast_rsqrt(d));  // (the last block row is stored scaled)
   }
 }
 
@@ -925,8 +947,8 @@ __global__ __launch_bounds__(256) void trsm_strip128_kernel(const double* __rest
 // The leaf asks for more LDS than it uses, so that no 72 KB GEMM workgroup fits beside it on a CU: since round 5 its
 // registers (152) would fit beside a bulk wave on a SIMD, and a chain wave that shares the SIMD's fp64 pipe with MFMA-saturated
 // waves runs about half as fast (N = 16384: 25.8 -> 26.2 ms when the two were allowed to share).
-constexpr size_t LEAF_LDS_USED = sizeof(double) * (LEAF_ELEMS + 2 * LEAF + 2 * SB + 4);
-constexpr size_t LEAF_LDS_BYTES = LEAF_LDS_USED > 96 * 1024 ? LEAF_LDS_USED : 96 * 1024;
+constexpr size_t LEAF_LDS_BYTES = sizeof(double) * (LEAF_ELEMS + 2 * LEAF + 4 * SB * YB_LD + 36 * MT_ELEMS + 4);
+static_assert(LEAF_LDS_BYTES > 96 * 1024 && LEAF_LDS_BYTES <= 160 * 1024, "the leaf takes a CU's LDS to itself");
 
 hipError_t leaf_enable_lds() {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_leaf128_kernel),

@@ -1,4 +1,5 @@
-// Dev harness: phase breakdown of potrf_leaf128 (s_memtime stamps) and of trsm_strip128.
+// Dev harness: correctness of potrf_leaf128 (L L^T = A, M L = I) and its timeline: one s_memtime probe per launch at a
+// selected program point (see LEAF_PROBE in leaf_f64.hip), so the probes do not perturb what they measure.
 #ifndef NO_STAMPS
 #define LEAF_STAMPS
 #endif
@@ -9,13 +10,6 @@
 #include <cmath>
 #include <random>
 using namespace migp;
-#ifdef LEAF_STAMPS
-#define STAMPS_RESET() hipMemcpyToSymbol(HIP_SYMBOL(g_leaf_stamps), z, sizeof(z))
-#define STAMPS_READ() hipMemcpyFromSymbol(st, HIP_SYMBOL(g_leaf_stamps), sizeof(st))
-#else
-#define STAMPS_RESET() (void)z
-#define STAMPS_READ() memset(st, 0, sizeof(st))
-#endif
 int main() {
   const int n = 128; const long lda = 144;
   std::vector<double> A(n * lda, 0.0), G(n * n);
@@ -25,38 +19,40 @@ int main() {
   std::vector<double> A0 = A;
   double *dA, *dinv; int* info; hipMalloc(&dA, A.size() * 8); hipMalloc(&dinv, 16384 * 8); hipMemset(dinv, 0, 16384 * 8); hipMalloc(&info, 16);
   leaf_enable_lds();
-  unsigned long long z[32] = {0};
   float best = 1e9;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int rep = 0; rep < 20; ++rep) {
+  auto run = [&]() {
     hipMemcpy(dA, A0.data(), A.size() * 8, hipMemcpyHostToDevice);
     hipMemset(info, 0x7f, 16);
-    STAMPS_RESET();
     hipEventRecord(e0); launch_potrf_leaf128(dA, lda, dinv, 0, info, 0); hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); best = std::min(best, ms);
-  }
-  unsigned long long st[32]; STAMPS_READ();
-  printf("leaf kernel %.1f us\n", best * 1e3);
-  printf("wave 0 cycles (8 blocks): load panel %llu | elimination %llu | scale+write+flag %llu | next diagonal tile %llu | wait urgent %llu | final barrier %llu\n", st[0], st[24]+st[25]+st[26]+st[27]+st[28]+st[29]+st[30]+st[31], st[2], st[3], st[4], st[5]);
-  printf("elimination per block:"); for (int i = 24; i < 32; ++i) printf(" %llu", st[i]); printf("\n");
-  printf("wave 1 cycles: initial load %llu | wait ready %llu | urgent %llu | lazy %llu | stream out %llu\n", st[8], st[9], st[10], st[11], st[12]);
-  printf("inverse (thread 0): dinv compute %llu | dinv write+sync %llu | stage A %llu | stage B %llu | rest %llu\n", st[16], st[17], st[18], st[19], st[20]);
+  };
+  for (int rep = 0; rep < 20; ++rep) run();
+  printf("leaf kernel %.1f us (events, best of 20)\n", best * 1e3);
+#ifdef LEAF_STAMPS
+  auto probe = [&](int code) {
+    unsigned long long zero = 0, out = 0, lo = ~0ull;
+    for (int rep = 0; rep < 3; ++rep) {
+      hipMemcpyToSymbol(HIP_SYMBOL(g_leaf_probe_sel), &code, sizeof(int));
+      hipMemcpyToSymbol(HIP_SYMBOL(g_leaf_probe_out), &zero, sizeof(zero));
+      run();
+      hipMemcpyFromSymbol(&out, HIP_SYMBOL(g_leaf_probe_out), sizeof(out));
+      if (out && out < lo) lo = out;
+    }
+    return lo == ~0ull ? 0ull : lo;
+  };
+  printf("cycles since the wave's start (s_memtime ticks), one probe per launch, min of 3\n");
+  printf("wave 0  jb: iteration start | panel loaded | eliminated | published + own rows written | next diagonal tile | urgent tiles seen\n");
+  for (int jb = 0; jb < 8; ++jb) { printf("  %d:", jb); for (int k = 0; k < 6; ++k) printf(" %7llu", probe(8 * jb + k)); printf("\n"); }
+  printf("wave 0 end of loop: %llu\n", probe(63));
+  printf("wave 1  initial load done: %llu\n", probe(62));
+  printf("wave 1  jb: ready seen | urgent arrived | lazy done | block row of M done | stream-out issued | T of next row done\n");
+  for (int jb = 0; jb < 8; ++jb) { printf("  %d:", jb); for (int k = 0; k < 6; ++k) printf(" %7llu", probe(64 + 8 * jb + k)); printf("\n"); }
+#endif
   hipMemcpy(A.data(), dA, A.size() * 8, hipMemcpyDeviceToHost);
-  // check L L^T = A0
   double err = 0;
   for (int i = 0; i < n; ++i) for (int j = 0; j <= i; ++j) { double s = 0; for (int k = 0; k <= j; ++k) s += A[i * lda + k] * A[j * lda + k]; err = std::max(err, std::fabs(s - A0[i * lda + j])); }
   printf("max |L L^T - A| = %.3e\n", err);
-  {  // per 16x16 block error against a host Cholesky
-    std::vector<double> R = A0;
-    for (int j = 0; j < n; ++j) {
-      double d = R[j * lda + j]; for (int k = 0; k < j; ++k) d -= R[j * lda + k] * R[j * lda + k];
-      d = std::sqrt(d); R[j * lda + j] = d;
-      for (int i = j + 1; i < n; ++i) { double v = R[i * lda + j]; for (int k = 0; k < j; ++k) v -= R[i * lda + k] * R[j * lda + k]; R[i * lda + j] = v / d; }
-    }
-    printf("block errors vs host Cholesky (row block down, column block across):\n");
-    for (int rb = 0; rb < 8; ++rb) { for (int cb = 0; cb <= rb; ++cb) { double e = 0; for (int i = 0; i < 16; ++i) for (int j = 0; j < 16; ++j) { int r = 16 * rb + i, c = 16 * cb + j; if (c <= r) { double dd = std::fabs(A[r * lda + c] - R[r * lda + c]); if (!(dd <= 1e300)) dd = 1e300; e = std::max(e, dd); } } printf(" %8.1e", e); } printf("\n"); }
-  }
-  // check M L = I (M = the explicit inverse the leaf streams out; tiles above the block diagonal are never written)
   std::vector<double> M(n * n);
   hipMemcpy(M.data(), dinv, M.size() * 8, hipMemcpyDeviceToHost);
   double ierr = 0;

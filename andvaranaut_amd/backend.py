@@ -220,10 +220,19 @@ class MiGP:
         are not uploaded: until the next finite update lml / lml_grad return -inf like a non-positive-definite covariance
         (the reference's graph would produce NaN and PyMC's checks reject the point)."""
         self._factored_ok = False
-        bad = (X is not None and not np.isfinite(np.asarray(X, dtype=np.float64)).all()) or \
-              (y is not None and not np.isfinite(np.asarray(y, dtype=np.float64)).all())
-        self._bad_data = bool(bad)
-        if bad:
+        # Each array carries its own state: a non-finite one is not uploaded and stays "bad" until a finite replacement
+        # arrives, the finite member of a pair IS uploaded (round 4 dropped it: a later update of the other array then
+        # evaluated against stale data).
+        if X is not None:
+            self._bad_X = not np.isfinite(np.asarray(X, dtype=np.float64)).all()
+            if self._bad_X:
+                X = None
+        if y is not None:
+            self._bad_y = not np.isfinite(np.asarray(y, dtype=np.float64)).all()
+            if self._bad_y:
+                y = None
+        self._bad_data = bool(getattr(self, "_bad_X", False) or getattr(self, "_bad_y", False))
+        if X is None and y is None:
             return
         with torch.cuda.device(self.dev):
             if X is not None:
@@ -259,6 +268,8 @@ class MiGP:
         self._factored_ok = False
         self._u_theta_ok = False
         self._pred_count = 0
+        if self._bad_data:  # the resident arrays are not the caller's data (update_data refused a non-finite array)
+            raise FloatingPointError("the last update_data carried non-finite values: nothing to factorise")
         self.info = self._check(self.lib.mi_gp_factor(self.h, tp), "mi_gp_factor")
         if self.info == 0:
             self._factored_ok, self._factored_theta = True, theta.copy()

@@ -34,6 +34,9 @@ struct mi_gp_handle {
   unsigned sig_epoch;
   int sig_next;
   int wait_slot;                    // the slot that stands in for wait_ev
+  bool smo_supported;               // hipDeviceAttributeCanUseStreamWaitValue
+  int poll_limit_log2;              // option 27: an in-kernel poll gives up after 2^this sleeps (default 22: seconds)
+  int test_drop_signal;             // option 28 (tests): the next evaluation leaves one main-stream signal unwritten
   int use_smo;                      // option 26: 0 events, 1 runtime stream memory operations, 2 (default) the panel stream's
                                     // halves folded into one-lane launches of the library / the end of a leaf
   // tuning options (mi_gp_set_option), all per handle
@@ -184,6 +187,17 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   h->asm_split = 1;
   h->asm_ev_valid = false;
   h->use_smo = 2;
+  {
+    // hipStreamWriteValue32 / hipStreamWaitValue32 need driver support: without it every two-stream evaluation would fail,
+    // so the edges fall back to events (option 26 = 0; mi_gp_set_option refuses 1 and 2 then)
+    int can = 0;
+    if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, h->device) != hipSuccess) can = 0;
+    (void)hipGetLastError();
+    h->smo_supported = can != 0;
+    if (!h->smo_supported) h->use_smo = 0;
+  }
+  h->poll_limit_log2 = 22;
+  h->test_drop_signal = 0;
   h->sig_epoch = 0;
   h->sig_next = 0;
   h->wait_slot = -1;
@@ -257,7 +271,9 @@ extern "C" int mi_gp_set_option(mi_gp_handle* h, int what, int value) {
   else if (what == 20) h->merge_min_tiles = value;
   else if (what == 21) h->single_below = value;
   else if (what == 24) h->asm_split = value ? 1 : 0;
-  else if (what == 26) h->use_smo = value < 0 ? 0 : value > 2 ? 2 : value;
+  else if (what == 26) h->use_smo = !h->smo_supported ? 0 : value < 0 ? 0 : value > 2 ? 2 : value;
+  else if (what == 27) h->poll_limit_log2 = value < 4 ? 4 : value > 30 ? 30 : value;
+  else if (what == 28) h->test_drop_signal = value ? 1 : 0;
   else if (what == 9) h->tail_small = value ? 1 : 0;
   else {
     snprintf(h->err, sizeof(h->err), "mi_gp_set_option: unknown option %d", what);
@@ -357,7 +373,7 @@ static hipError_t chol_panel(mi_gp_handle* h, double* A, long lda, int ntr, int 
     const bool waits = c0 == h->wait_col;
     const bool folded = waits && h->wait_slot >= 0 && h->use_smo >= 2;
     e = launch_potrf_leaf128(blk, lda, dinv, c0 * 128, h->info_dev, st, m == 128 ? blk + 128 * lda : nullptr, h->btp,
-                             folded ? h->sig_dev + h->wait_slot : nullptr, h->sig_epoch);
+                             folded ? h->sig_dev + h->wait_slot : nullptr, h->sig_epoch, h->poll_limit_log2);
     if (e == hipSuccess && m > 128) e = launch_trsm_strip128(dinv, blk + 128 * lda, lda, m, st, h->btp, h->btp ? h->btp->sK : 0);
     if (e == hipSuccess && waits) {
       h->wait_col = -1;
@@ -488,7 +504,8 @@ static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int nt
       if (h->use_smo >= 2 && tp_edge && h->sig_next + 2 <= SIG_SLOTS) {
         const int a = h->sig_next++;
         tp_slot = h->sig_next++;
-        CKE(launch_signal_write_wait(h->sig_dev + a, h->sig_dev + tp_slot, h->sig_epoch, h->info_dev, P));
+        CKE(launch_signal_write_wait(h->sig_dev + a, h->sig_dev + tp_slot, h->sig_epoch, h->info_dev, P, h->btp ? h->btp->nb : 1,
+                                     h->btp ? h->btp->sinfo : 0, h->poll_limit_log2));
         CKE(hipStreamWaitValue32(T, h->sig_dev + a, h->sig_epoch, hipStreamWaitValueGte, 0xffffffffu));
       } else {
         CKE(hand_off(h, P, T));
@@ -546,7 +563,14 @@ static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int nt
       CKE(syrk_trapezoid(h, A, lda, ntr, n1, 1, J, w, P));
       if (wn > 1) {
         CKE(syrk_trapezoid(h, A, lda, ntr, n1 + 1, wn - 1, J, w, T));
-        h->wait_slot = signal_from(h, T, &e);
+        if (h->test_drop_signal && h->use_smo && h->sig_next < SIG_SLOTS) {
+          // test hook (option 28): this edge's slot is never written -- the panel stream's poll has to give up
+          h->test_drop_signal = 0;
+          h->wait_slot = h->sig_next++;
+          e = hipSuccess;
+        } else {
+          h->wait_slot = signal_from(h, T, &e);
+        }
         if (e != hipSuccess) return e;
         if (h->wait_slot < 0) {
           CKE(next_event(h, &h->wait_ev));
@@ -597,7 +621,10 @@ static int enqueue_factor(mi_gp_handle* h, int noise_form, bool prof) {
   // are assembled first; the rest follows on the main stream one workgroup per CU, beside that factorisation (option 24).
   h->asm_ev_valid = false;
   const bool two_stream = h->lookahead == 2 || (h->lookahead == 1 && h->ntc >= LOOKAHEAD_MIN_TILES);
-  const int w0 = h->cfg.panel_tiles > 0 ? h->cfg.panel_tiles : 8;  // at least the first super-panel's columns
+  // the first super-panel's width, by the rule cholesky() applies (the panel stream is released behind these columns: with a
+  // narrower guess -- a hard-coded 8 until round 5, while option 4 makes the first panel 16 tiles wide -- the panel stream
+  // would factor columns the second assembly launch is still writing)
+  const int w0 = pick_w(h, h->ntc, (two_stream && h->ntc <= NARROW_PANELS_MAX_TILES) ? 4 : 0);
   const int c0 = (w0 * 128 + 511) / 512;
   if (h->asm_split && two_stream && !h->btp && h->ntc >= 96 && 4 * c0 < h->ntc) {  // (N = 8192: 5.62 -> 5.65 ms, N = 16384: 26.66 -> 26.57)
     HCK(launch_assemble(h->spec, h->theta_dev, h->buf.X_dev, h->n, h->buf.X_dev, h->n, h->buf.K_dev, h->buf.lda, h->np,
@@ -935,6 +962,14 @@ static int batch_internal(mi_gp_handle* h, int k, const double* thetas, int what
   h->out_host = out0; h->theta_host = thost0; h->info_dev = info0;
   h->lr_part_dev = lrp0; h->lr_sync_dev = lrs0;
   if (r != 0) return r;
+  // a cross-stream poll that gave up leaves unsynchronised data behind in EVERY problem: the whole batch fails (round 4
+  // reported such a batch as k non-positive-definite points)
+  for (int p = 0; p < k; ++p) {
+    if ((int)h->b_out_host[16 * p + 3] == SIGNAL_TIMEOUT_INFO) {
+      snprintf(h->err, sizeof(h->err), "a cross-stream signal of the batched factorisation was not seen within its poll limit");
+      return -2;
+    }
+  }
   for (int p = 0; p < k; ++p) {
     const int info = (int)h->b_out_host[16 * p + 3];
     const bool ok = info == 0x7f7f7f7f;

@@ -796,11 +796,12 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
 // the panel stream's wait for the main stream's next-panel update into the leaf that precedes the first reader of those
 // columns: one polling lane at the end of a kernel that is a single workgroup anyway, instead of a runtime wait kernel of
 // 5-9 us on the chain).  The poll gives up after ~2^22 sleeps (seconds) and reports through the bad-pivot word.
-__device__ __forceinline__ void poll_signal(const unsigned* ptr, unsigned val, int* info) {
+__device__ __forceinline__ void poll_signal(const unsigned* ptr, unsigned val, int* info, int limit_log2) {
   long spins = 0;
+  const long limit = 1L << limit_log2;
   while (__hip_atomic_load(ptr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < val) {
     __builtin_amdgcn_s_sleep(4);
-    if (++spins > (1L << 22)) {
+    if (++spins > limit) {
       atomicMin(info, SIGNAL_TIMEOUT_INFO);
       break;
     }
@@ -810,26 +811,34 @@ __device__ __forceinline__ void poll_signal(const unsigned* ptr, unsigned val, i
 __global__ __launch_bounds__(256, 1) void potrf_leaf128_kernel(double* __restrict__ Ablk, long lda,
                                                                 double* __restrict__ minv, int col0,
                                                                 int* __restrict__ info, double* yrow, long sA, long sminv,
-                                                                int sinfo, const unsigned* wait_ptr, unsigned wait_val) {
+                                                                int sinfo, const unsigned* wait_ptr, unsigned wait_val,
+                                                                int poll_log2) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   __builtin_amdgcn_s_setprio(3);  // the leaf is the panel chain: win the issue arbitration against bulk GEMM waves on its CU
   const long z = blockIdx.x;  // batched evaluation: one workgroup per problem
   potrf_leaf128_body(Ablk + z * sA, lda, minv + z * sminv, col0, info + z * sinfo, smem, yrow ? yrow + z * sA : nullptr);
-  if (wait_ptr != nullptr && threadIdx.x == 0) poll_signal(wait_ptr, wait_val, info + z * sinfo);
+  if (wait_ptr != nullptr && threadIdx.x == 0) poll_signal(wait_ptr, wait_val, info + z * sinfo, poll_log2);
 }
 
 // One lane: raise *wr to `val` (if wr) and then wait for *wt >= val (if wt).  The panel stream's two edges at a
 // super-panel boundary -- tell the main stream the panel is done, wait for the main stream's previous bulk update -- in
 // ONE launch instead of two runtime kernels (hipStreamWriteValue32 + hipStreamWaitValue32, ~5 us each on the chain).
-__global__ void signal_write_wait_kernel(unsigned* wr, const unsigned* wt, unsigned val, int* info) {
+// A poll that gives up marks the bad-pivot word of EVERY problem of a batch (nb words, sinfo apart).
+__global__ void signal_write_wait_kernel(unsigned* wr, const unsigned* wt, unsigned val, int* info, int nb, int sinfo, int poll_log2) {
   if (threadIdx.x == 0) {
     if (wr != nullptr) __hip_atomic_store(wr, val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (wt != nullptr) poll_signal(wt, val, info);
+    if (wt != nullptr) {
+      int local = 0x7f7f7f7f;
+      poll_signal(wt, val, &local, poll_log2);
+      if (local == SIGNAL_TIMEOUT_INFO)
+        for (int p = 0; p < nb; ++p) atomicMin(info + (long)p * sinfo, SIGNAL_TIMEOUT_INFO);
+    }
   }
 }
 
-hipError_t launch_signal_write_wait(unsigned* wr, const unsigned* wt, unsigned val, int* info, hipStream_t stream) {
-  signal_write_wait_kernel<<<1, 64, 0, stream>>>(wr, wt, val, info);
+hipError_t launch_signal_write_wait(unsigned* wr, const unsigned* wt, unsigned val, int* info, hipStream_t stream, int nb, int sinfo,
+                                    int poll_log2) {
+  signal_write_wait_kernel<<<1, 64, 0, stream>>>(wr, wt, val, info, nb, sinfo, poll_log2);
   return hipGetLastError();
 }
 
@@ -957,9 +966,10 @@ hipError_t leaf_enable_lds() {
 }
 
 hipError_t launch_potrf_leaf128(double* Ablk, long lda, double* minv, int col0, int* info, hipStream_t stream, double* yrow,
-                                const Batch* bt, const unsigned* wait_ptr, unsigned wait_val) {
+                                const Batch* bt, const unsigned* wait_ptr, unsigned wait_val, int poll_log2) {
   potrf_leaf128_kernel<<<bt ? bt->nb : 1, 256, LEAF_LDS_BYTES, stream>>>(Ablk, lda, minv, col0, info, yrow, bt ? bt->sK : 0,
-                                                                        bt ? bt->sdinv : 0, bt ? bt->sinfo : 0, wait_ptr, wait_val);
+                                                                        bt ? bt->sdinv : 0, bt ? bt->sinfo : 0, wait_ptr, wait_val,
+                                                                        poll_log2);
   return hipGetLastError();
 }
 

@@ -87,10 +87,12 @@ constexpr int MINV_ELEMS = 128 * 128;  // doubles per leaf inverse
 // wait_ptr (optional): the launch ends only once *wait_ptr >= wait_val (a cross-stream signal; see leaf_f64.hip)
 hipError_t launch_potrf_leaf128(double* Ablk, long lda, double* minv, int col0, int* info, hipStream_t stream,
                                 double* yrow = nullptr, const Batch* bt = nullptr, const unsigned* wait_ptr = nullptr,
-                                unsigned wait_val = 0);
-// one lane: *wr = val (if wr), then wait for *wt >= val (if wt); a poll that gives up puts SIGNAL_TIMEOUT_INFO into *info
+                                unsigned wait_val = 0, int poll_log2 = 22);
+// one lane: *wr = val (if wr), then wait for *wt >= val (if wt); a poll that gives up (after 2^poll_log2 sleeps) puts
+// SIGNAL_TIMEOUT_INFO into the nb bad-pivot words info[p * sinfo]
 constexpr int SIGNAL_TIMEOUT_INFO = -99;
-hipError_t launch_signal_write_wait(unsigned* wr, const unsigned* wt, unsigned val, int* info, hipStream_t stream);
+hipError_t launch_signal_write_wait(unsigned* wr, const unsigned* wt, unsigned val, int* info, hipStream_t stream, int nb = 1,
+                                    int sinfo = 0, int poll_log2 = 22);
 // X * L^T = B in place on the m x 128 panel B (m multiple of 16, ldb even) as X = B * M^T with the leaf's inverse M.
 hipError_t launch_trsm_strip128(const double* minv, double* B, long ldb, int m, hipStream_t stream, const Batch* bt = nullptr,
                                 long sB2 = 0);

@@ -93,6 +93,7 @@ class DistGP:
             # then the one a multi-GPU run takes); without one there is nothing to exchange.
             self.collective = dist.is_initialized()
         self.bytes_broadcast = 0
+        self.lazy_sends = None  # None: by world size (see lml); True / False: the owner never / always waits for its panel sends
         X = np.ascontiguousarray(X, dtype=np.float64)
         y = np.ascontiguousarray(np.asarray(y, dtype=np.float64).reshape(-1))
         self.n, self.d = X.shape
@@ -219,7 +220,15 @@ class DistGP:
             # (Only RCCL runs a communicator's collectives strictly one after the other.  gloo -- the tests' transport -- may
             # run two at once: there a later receive into a buffer could overtake this rank's own send out of it to a slow
             # peer, so with any other backend the owner waits for its sends at once, as it did until round 4.)
-            lazy_sends = (not self.collective) or dist.get_backend() == "nccl"
+            # Lazy sends on a real multi-rank RCCL job have never run on hardware (no multi-GPU box in rounds 1-5): they are
+            # opt-in there (``lazy_sends = True``) until a 2-GPU run has shown lazy and eager results bit-equal; a one-rank
+            # communicator (every panel is the rank's own) and the emulation keep them.
+            if not self.collective:
+                lazy_sends = True
+            elif self.lazy_sends is not None:
+                lazy_sends = bool(self.lazy_sends) and dist.get_backend() == "nccl"
+            else:
+                lazy_sends = dist.get_backend() == "nccl" and self.world == 1
             work = self._exchange(0)  # panel 0 was staged on the main stream by its owner
             if owner(0) == self.rank:
                 if work is not None and not lazy_sends:

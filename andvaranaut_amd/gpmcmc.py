@@ -560,10 +560,17 @@ class GPMCMC(ConsumersMixin):
             except Exception as e:  # noqa: BLE001
                 errors.append(e)
 
+        def batch_fits(dev, nchain):
+            """One handle's batch buffers: nchain copies of K, U and K^-1 (the lanes path sizes itself the same way)."""
+            npad = (len(yin) + 127) // 128 * 128
+            need = nchain * (3 * (npad + 128) * (npad + 16) + (npad // 128) * 128 * 128) * 8
+            free, _total = torch.cuda.mem_get_info(dev)
+            return need <= 0.8 * free
+
         threads = []
         use_batch = (batched if batched is not None else True) and not (iwgp or cwgp)
         for dev, cs in by_dev.items():
-            if use_batch and len(cs) > 1 and chains_per_device is None:
+            if use_batch and len(cs) > 1 and chains_per_device is None and batch_fits(dev, len(cs)):
                 threads.append(threading.Thread(target=run_batched, args=(dev, cs, gp if dev == self.device else None)))
                 continue
             k = lanes_for(dev, len(cs))

@@ -134,7 +134,7 @@ int mi_gp_predict_grad(mi_gp_handle* h, const double* Xnew_dev, int m, double* w
 
 /* tuning knobs (benchmarks / A-B tests), ALL per handle -- nothing here is process-wide:
  *   0  look-ahead: factor the next super-panel on a second stream while the trailing update runs; 0 never, 1 by size
- *      (default: from 36 tile columns = N > 4480 on, where the overlap beats the cross-stream hand-offs), 2 always
+ *      (default: from 20 tile columns = N > 2432 on, where the overlap beats the cross-stream hand-offs), 2 always
  *   2  super-panel width in 128-column tiles (default 0 = by trailing size, options 4-6)
  *   4-6  trailing sizes (tile columns) above which the super-panel is 16 / 8 / 4 tiles wide (below the last: 2);
  *        defaults: never 16, else 8; with look-ahead active, problems of up to 64 tile columns use at most 4
@@ -156,8 +156,15 @@ int mi_gp_predict_grad(mi_gp_handle* h, const double* Xnew_dev, int m, double* w
  *      instead of 11-12 on MI355X; N = 6144 3.40 -> 3.26 ms); 2 (default) the same protocol with the PANEL stream's halves
  *      folded into launches of the library: its write + wait at a super-panel boundary is one one-lane launch, its wait
  *      for the next-panel update is a poll at the end of the leaf in front of the first reader (N = 4096 1.995 -> 1.965 ms).
- *      A poll that sees nothing for seconds gives up and the evaluation returns -2.
- * 8, 14, 16, 18, 19, 21, 24 and 26 only change scheduling (bit-identical results); 20 moves tiles between the two GEMM kernels (same k order); 2, 4-7, 9 regroup sums (agreement to rounding), and so does 0 where
+ *      A poll that sees nothing for seconds gives up and the evaluation (a batch: the whole batch) returns -2 with
+ *      "a cross-stream signal ... was not seen within its poll limit"; the handle stays usable.  Modes 1 and 2 need
+ *      hipDeviceAttributeCanUseStreamWaitValue: mi_gp_create queries it and falls back to 0 (the option then stays 0
+ *      whatever is set).  The panel stream's polls are enqueued ahead of the main-stream writes they wait for, which is
+ *      safe while the two streams of a handle do not queue behind each other in one hardware queue: keep at most six
+ *      handles evaluating concurrently per device with mode 2 (tests run six), or use mode 0 / 1 beyond that.
+ *   27 log2 of the number of sleeps after which such a poll gives up (default 22 = seconds; 4 .. 30)
+ *   28 test hook: the next two-stream evaluation leaves one main-stream signal unwritten (its poll must give up)
+ * 8, 14, 16, 18, 19, 21, 24, 26 and 27 only change scheduling (bit-identical results); 20 moves tiles between the two GEMM kernels (same k order); 2, 4-7, 9 regroup sums (agreement to rounding), and so does 0 where
  * it changes the super-panel width (20 to 60 tile columns).
  * Unknown ids return -1.  (Round 1's options 1, 3, 10-13 -- GEMM variants, hipGraph replay, persistent bulk kernels,
  * exclusive leaf, fused leaf + strip -- are gone with the code they selected.) */

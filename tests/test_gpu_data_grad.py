@@ -244,3 +244,38 @@ def test_data_and_predictive_gradients_beyond_128_input_dimensions(N, d, kernel)
     assert np.abs(dmu - dmu_o).max() <= 1e-7 * np.abs(dmu_o).max()
     assert np.abs(dvar - dvar_o).max() <= 1e-7 * np.abs(dvar_o).max()
     gp.close()
+
+
+def test_update_data_uploads_the_finite_member_of_a_pair_and_factor_refuses_bad_data():
+    """update_data(X=bad, y=new) dropped y; a later update_data(X=good) then evaluated against the stale y."""
+    import torch
+
+    assert torch.cuda.is_available()
+    from andvaranaut_amd import MiGP
+    from oracle import gp_oracle as orc
+
+    N, d = 300, 3
+    X, y = orc.synth_problem(N, d, seed=2)
+    theta = orc.synth_theta(d)
+    gp = MiGP(X, y, "RBF")
+    y2 = y[::-1].copy()
+    Xbad = X.copy()
+    Xbad[5, 1] = np.nan
+    gp.update_data(X=Xbad, y=y2)
+    assert gp.lml(theta) == -np.inf
+    with pytest.raises(FloatingPointError):
+        gp.factor(theta)
+    gp.update_data(X=X)  # y2 must be resident by now
+    ref = orc.lml(X, y2, ["RBF"], [], theta)
+    val = gp.lml(theta)
+    assert abs(val - ref) <= 1e-10 * abs(ref), (val, ref)
+    # a bad y alone keeps the handle "bad" until a finite y arrives, whatever happens to X
+    ybad = y.copy()
+    ybad[0] = np.inf
+    gp.update_data(y=ybad)
+    gp.update_data(X=X)
+    assert gp.lml(theta) == -np.inf
+    gp.update_data(y=y)
+    ref = orc.lml(X, y, ["RBF"], [], theta)
+    assert abs(gp.lml(theta) - ref) <= 1e-10 * abs(ref)
+    gp.close()

@@ -132,11 +132,40 @@ def test_config4_shape_fits_one_gpu():
     assert gp.info == 0 and np.isfinite(v1)
     logdet, quad = gp.lml_parts()
     assert abs(v1 - (-0.5 * N * np.log(2 * np.pi) - 0.5 * quad - logdet)) <= 1e-12 * abs(v1)
+    # ORACLE-TIED at the full size: 256 random rows of L L^T, formed on the device in fp64 from the
+    # factor the library left in K_t, against the same rows of the oracle's noisy covariance assembled on the host
+    # (O(256 N d)); bound 64 N eps of the largest entry (observed: ~1e-13)
+    import torch
+    from oracle import gp_oracle as orc
+
+    rows = np.sort(np.random.default_rng(7).choice(N, 256, replace=False))
+    Kref = orc.kernel_matrix(X[rows], X, ["RBF"], [], theta)
+    sg = np.sqrt(theta[-2])
+    Kref[np.arange(256), rows] += sg * sg
+    Kref[np.arange(256), rows] += theta[-1]
+    with torch.cuda.device(gp.dev):
+        rt = torch.from_numpy(rows).to(gp.dev)
+        cols = torch.arange(N, device=gp.dev)
+        Lr = gp.K_t[rt, :N] * (cols[None, :] <= rt[:, None])  # the rows' lower-triangular part (the strict upper triangle of K_t is never written)
+        llt = torch.empty((256, N), dtype=torch.float64, device=gp.dev)
+        for j0 in range(0, N, 8192):  # tril of 8192 rows of L at a time (4 GB), not of the whole 34 GB factor
+            Lj = gp.K_t[j0:j0 + 8192, :N] * (cols[None, :] <= (j0 + torch.arange(8192, device=gp.dev))[:, None])
+            llt[:, j0:j0 + 8192] = Lr @ Lj.T
+            del Lj
+        res = float((llt - torch.from_numpy(Kref).to(gp.dev)).abs().max())
+        del llt, Lr
+    assert res <= 64 * N * np.finfo(float).eps * np.abs(Kref).max(), res
     assert gp.lml(theta) == v1
     # SURVEY 8e "gradient at C4 scale": no distributed inverse is needed, the whole gradient path fits one GPU.
     # Size-independent check: the directional derivative along the gradient against a central difference of the LML.
     v2, g = gp.lml_grad(theta)
     assert abs(v2 - v1) <= 1e-12 * abs(v1) and np.all(np.isfinite(g))
+    # ... and the oracle's rows times the device's alpha = K^-1 y reproduce y (residual relative to |K| |alpha| + |y|)
+    _, _, neg_alpha, _ = gp.lml_grad_data(theta, want_x=False)
+    alpha = -neg_alpha
+    resid = np.abs(Kref @ alpha - y[rows])
+    scale = np.abs(Kref) @ np.abs(alpha) + np.abs(y[rows])
+    assert (resid / scale).max() <= 64 * N * np.finfo(float).eps, (resid / scale).max()
     u = g / np.linalg.norm(g)
     h = 1e-4
     tp, tm = theta.copy(), theta.copy()

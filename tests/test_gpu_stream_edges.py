@@ -1,0 +1,107 @@
+"""Robustness of the two-stream factorisation's cross-stream edges (stream memory operations, in-kernel polls) and of
+the option combinations ADVICE r4 named.  The reference returns errors from inside the optimiser loop instead of throwing
+(gpmcmc.py:331-339): a poll that gives up must come back as an error code with the handle still usable."""
+import threading
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _mods():
+    import torch
+
+    assert torch.cuda.is_available()
+    from andvaranaut_amd import MiGP
+    from oracle import gp_oracle as orc
+
+    return MiGP, orc
+
+
+def test_poll_that_sees_nothing_gives_up_with_an_error_and_the_handle_survives():
+    MiGP, orc = _mods()
+    N, d = 4096, 8  # 32 tile columns: two streams, the (a2) edge is a poll at the end of a leaf
+    X, y = orc.synth_problem(N, d, seed=3)
+    theta = orc.synth_theta(d)
+    gp = MiGP(X, y, "RBF", need_grad=False)
+    ref = gp.lml(theta)
+    assert gp.info == 0
+    gp.set_option(27, 12)  # give up after 2^12 sleeps (well under a millisecond) instead of seconds
+    gp.set_option(28, 1)   # the next evaluation leaves one main-stream signal unwritten
+    t0 = time.perf_counter()
+    with pytest.raises(RuntimeError, match="cross-stream signal .* not seen within its poll limit"):
+        gp.lml(theta)
+    assert time.perf_counter() - t0 < 1.0
+    # the next evaluation runs on a new epoch: same bits as before the failure
+    assert gp.lml(theta) == ref and gp.info == 0
+    gp.set_option(27, 22)
+    assert gp.lml(theta) == ref
+    gp.close()
+
+
+def test_batch_with_a_poll_timeout_fails_as_a_whole():
+    MiGP, orc = _mods()
+    N, d = 4096, 8
+    X, y = orc.synth_problem(N, d, seed=4)
+    th = np.stack([orc.synth_theta(d, kv=1.5 + 0.1 * i) for i in range(3)])
+    gp = MiGP(X, y, "RBF", need_grad=False)
+    ref = gp.lml_batch(th)
+    gp.set_option(27, 12)
+    gp.set_option(28, 1)
+    with pytest.raises(RuntimeError, match="poll limit"):
+        gp.lml_batch(th)
+    assert np.array_equal(gp.lml_batch(th), ref)
+    gp.close()
+
+
+def test_six_handles_evaluating_concurrently_on_two_streams_each():
+    """Six handles x two streams with in-kernel polls (option 26 = 2): no poll-limit error, every value equal to the serial
+    schedule's (include/mi_gp.h documents six as the tested limit for mode 2)."""
+    MiGP, orc = _mods()
+    N, d = 3072, 6  # 24 tile columns: the two-stream driver
+    X, y = orc.synth_problem(N, d, seed=9)
+    thetas = [orc.synth_theta(d, kv=1.2 + 0.05 * i) for i in range(12)]
+    gps = [MiGP(X, y, "Matern52", need_grad=False) for _ in range(6)]
+    serial = [gps[0].lml(t) for t in thetas]
+    out = [[None] * len(thetas) for _ in gps]
+    errs = []
+
+    def work(i):
+        try:
+            for rep in range(3):
+                for j, t in enumerate(thetas):
+                    out[i][j] = gps[i].lml(t)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(len(gps))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for i in range(len(gps)):
+        assert out[i] == serial
+    for g in gps:
+        g.close()
+
+
+def test_assembly_split_follows_the_first_super_panel_width():
+    """with option 4 the first super-panel is 16 tiles wide; the split assembly (option 24) used to release the panel
+    stream behind 8 tiles' columns only.  Same bits with the split on and off."""
+    MiGP, orc = _mods()
+    N, d = 12288, 8
+    X, y = orc.synth_problem(N, d, seed=11)
+    theta = orc.synth_theta(d)
+    gp = MiGP(X, y, "RBF", need_grad=False)
+    gp.set_option(4, 64)  # 16-tile super-panels while more than 64 tile columns remain
+    gp.set_option(24, 0)
+    a = gp.lml(theta)
+    gp.set_option(24, 1)
+    vals = [gp.lml(theta) for _ in range(4)]
+    assert gp.info == 0 and all(v == a for v in vals), (a, vals)
+    ref = orc.lml(X, y, ["RBF"], [], theta)
+    assert abs(a - ref) <= 1e-10 * abs(ref)
+    gp.close()

@@ -94,6 +94,12 @@ class DistGP:
             self.collective = dist.is_initialized()
         self.bytes_broadcast = 0
         self.lazy_sends = None  # None: by world size (see lml); True / False: the owner never / always waits for its panel sends
+        # "bcast": one dist.broadcast per piece (RCCL's ring / tree out of the owner).  "mesh": the owner sends 1/(W-1) of a
+        # piece to every peer over that peer's own xGMI link and the peers all-gather among themselves -- two transfers of
+        # bytes/(W-1) per link instead of one of `bytes` over one link (see _mesh).  UNVERIFIED on hardware (no multi-GPU box
+        # in rounds 1-5): opt-in, covered by the gloo multi-rank tests through host staging.
+        self.exchange = "bcast"
+        self.peer_groups = None
         X = np.ascontiguousarray(X, dtype=np.float64)
         y = np.ascontiguousarray(np.asarray(y, dtype=np.float64).reshape(-1))
         self.n, self.d = X.shape
@@ -116,7 +122,9 @@ class DistGP:
             self.y_t = torch.from_numpy(y).to(self.dev)
             self.K = torch.zeros((rows, self.ld), dtype=torch.float64, device=self.dev)
             # piece-major panel buffers: piece c = tile column c of a panel (its rows at a stride of 128, then its leaf inverse)
-            self.P = [torch.zeros((self.pwt, rows + DINV_ROWS, 128), dtype=torch.float64, device=self.dev) for _ in range(2)]
+            # (+ world rows: the mesh exchange pads a piece to a multiple of world - 1 chunks)
+            self.P = [torch.zeros((self.pwt, rows + DINV_ROWS + self.world, 128), dtype=torch.float64, device=self.dev) for _ in range(2)]
+            self.xfer = torch.cuda.Stream(device=self.dev)  # the mesh exchange's receive -> all-gather sequence
             self.theta_t = torch.zeros(self.ntheta, dtype=torch.float64, device=self.dev)
             self.info = torch.zeros(4, dtype=torch.int32, device=self.dev)
             self.out = torch.zeros(16, dtype=torch.float64, device=self.dev)
@@ -295,13 +303,22 @@ class DistGP:
             return float("nan")  # a single emulated rank holds only its share of the two sums
         return -0.5 * self.n * math.log(2.0 * math.pi) - 0.5 * quad - logdet
 
+    def set_exchange(self, mode):
+        """"bcast" (default) or "mesh"; collective: every rank has to make the same call (the peer groups are created here)."""
+        if mode not in ("bcast", "mesh"):
+            raise ValueError(mode)
+        if mode == "mesh" and self.collective and self.world > 2 and self.peer_groups is None:
+            # peer_groups[o]: everybody but rank o (the ranks that all-gather a piece owner o scattered)
+            self.peer_groups = [dist.new_group([r for r in range(self.world) if r != o]) for o in range(self.world)]
+        self.exchange = mode
+
     def _exchange(self, j):
         """Post the exchange of panel j under the current stream, one piece (tile column) at a time: the RCCL broadcasts
         from its owner -- who orders each behind that piece's staging -- or, emulating another rank's panel, copies from
         the complete factor on the stand-in link stream.  Returns something with .wait() (makes the then-current stream
         wait for the whole panel) or None when there is nothing to wait for."""
         if self.collective:
-            return self._bcast(j)
+            return self._mesh(j) if (self.exchange == "mesh" and self.world > 1) else self._bcast(j)
         if self.emulate and j % self.world != self.rank:
             return self._standin(j)
         return None  # this rank's own panel: nothing arrives, and nothing is sent in an emulation
@@ -334,6 +351,57 @@ class DistGP:
             self.bytes_broadcast += view.numel() * 8
             works.append(dist.broadcast(view, src=src, async_op=True))
         return _Works(works)
+
+    def _mesh(self, j):
+        """Panel j over the xGMI mesh, piece by piece: the owner sends chunk g (1 / (W - 1) of the piece's rows) to peer g --
+        W - 1 point-to-point sends in ONE grouped launch, one per outgoing link -- and the peers all-gather the chunks among
+        themselves (peer_groups[owner]), each over its links to the other peers.  Per link a piece costs 2 bytes / (W - 1)
+        instead of `bytes` for a broadcast that leaves the owner over one link (3.5 x at W = 8).  The receive and the
+        all-gather run on the transfer stream, ordered behind the stream the exchange was posted under (like _bcast); the
+        returned handle makes the then-current stream wait for the last all-gather.  With gloo (the tests' transport, no GPU
+        point-to-point) the chunks are staged through host memory, synchronously."""
+        W, o = self.world, j % self.world
+        rows = self._piece_rows(j) + DINV_ROWS
+        npeer = W - 1
+        cr = -(-rows // npeer)  # rows per chunk; the padding rows of the last chunk travel too (the buffers have room)
+        peers = [r for r in range(W) if r != o]
+        nccl = dist.get_backend() == "nccl"
+        cur = torch.cuda.current_stream(self.dev)
+        works = []
+        for c in range(self._w(j)):
+            padded = self.P[j % 2][c, : cr * npeer]
+            chunks = [padded[g * cr: (g + 1) * cr] for g in range(npeer)]
+            self.bytes_broadcast += padded.numel() * 8
+            if o == self.rank:
+                self._scheck(self.lib.mi_gp_shard_wait_piece(self.sh, c, self._stream()), "mi_gp_shard_wait_piece")
+                if nccl:
+                    works += dist.batch_isend_irecv([dist.P2POp(dist.isend, chunks[g], peers[g]) for g in range(npeer)])
+                else:
+                    for g in range(npeer):
+                        dist.send(chunks[g].cpu(), peers[g])  # (.cpu() is ordered behind the staging on the current stream)
+            else:
+                g = peers.index(self.rank)
+                if nccl:
+                    self.xfer.wait_stream(cur)
+                    with torch.cuda.stream(self.xfer):
+                        for w in dist.batch_isend_irecv([dist.P2POp(dist.irecv, chunks[g], o)]):
+                            w.wait()  # the transfer stream waits for the chunk (the compute streams do not)
+                        if npeer > 1:
+                            works.append(dist.all_gather_into_tensor(padded, chunks[g], group=self.peer_groups[o], async_op=True))
+                        else:
+                            ev = torch.cuda.Event()
+                            ev.record(self.xfer)
+                            works.append(_Arrived(self.dev, ev))
+                else:
+                    mine = torch.empty(chunks[g].shape, dtype=torch.float64)
+                    dist.recv(mine, o)
+                    parts = [mine]
+                    if npeer > 1:
+                        parts = [torch.empty_like(mine) for _ in range(npeer)]
+                        dist.all_gather(parts, mine, group=self.peer_groups[o])
+                    for q in range(npeer):
+                        chunks[q].copy_(parts[q])  # stream-ordered behind the earlier readers of this buffer
+        return _Works(works) if works else None
 
     # ------------------------------------------------------------------ gradient
     def _alloc_grad_buffers(self):

@@ -243,9 +243,9 @@ def sharded_record(args, rank, world, dev, N, d, kernel, steps, warmup, grad=Fal
             rec["single_gpu_check"] = f"skipped: {type(e).__name__}: {e}"
     # the one-GPU rank emulation's prediction for this world size (tools/emulate_rank.py --curve), for the first hardware
     # run to be checked against: a model (measured per-rank compute and owner chain + bytes / link bandwidth), not a result
-    mfile = os.path.join(ROOT, "profiles", "r04_sharded_model.json")
+    mfile = os.path.join(ROOT, "profiles", "r05_sharded_model.json")
     if not os.path.exists(mfile):
-        mfile = os.path.join(ROOT, "profiles", "r03_sharded_model.json")
+        mfile = os.path.join(ROOT, "profiles", "r04_sharded_model.json")
     if not grad and os.path.exists(mfile):
         try:
             mj = json.load(open(mfile))
@@ -253,10 +253,15 @@ def sharded_record(args, rank, world, dev, N, d, kernel, steps, warmup, grad=Fal
                 for pr in mj.get("prediction", []):
                     # the model file holds both chain placements for world > 1; the driver's default is "ahead of the bulk update"
                     # ... sending each tile column behind its strip (the first such entry; the whole-panel send follows it)
-                    if (pr.get("world") == world and pr.get("panel_tiles") == gp_pwt and "predicted_ms_per_step" not in rec
-                            and (world == 1 or pr.get("chain", "").startswith("on the main"))):
-                        rec["predicted_ms_per_step"] = pr["predicted_ms"]
-                        rec["prediction_source"] = f"profiles/{os.path.basename(mfile)} (one-GPU emulation of ranks + link model)"
+                    if (pr.get("world") == world and pr.get("panel_tiles") == gp_pwt
+                            and (world == 1 or (pr.get("chain", "").startswith("on the main") and pr.get("send", "").startswith("piece")))):
+                        # one entry per assumed one-way link bandwidth and exchange form (round 5): AMD's 153.6 GB/s per xGMI
+                        # link is most likely a bidirectional figure, so 77 GB/s one way is modelled beside it
+                        key = f"{pr.get('exchange', 'bcast')}@{pr.get('link_GBps_assumed', 153.0):g}GBps"
+                        rec.setdefault("predicted_ms_per_step_by_exchange_and_link", {})[key] = pr["predicted_ms"]
+                        if "predicted_ms_per_step" not in rec:
+                            rec["predicted_ms_per_step"] = pr["predicted_ms"]
+                            rec["prediction_source"] = f"profiles/{os.path.basename(mfile)} (one-GPU emulation of ranks + link model: a MODEL, not a measurement)"
         except Exception as e:  # noqa: BLE001
             rec["prediction_source"] = f"unreadable: {e}"
     return rec

@@ -135,6 +135,17 @@ for (N, d, kernel, pwt) in [(1500, 4, "RBF", None), (2100, 5, "Matern52", None),
     assert np.max(np.abs(g6 - g) / scale) <= 1e-9, (rank, N)
     gp.set_option(5, 2)
     assert gp.lml(theta) == val
+    # the mesh form of the exchange (owner scatters 1 / (W - 1) of every piece to each peer, the peers all-gather; under
+    # gloo through host staging): the same bytes arrive, so the same bits come out
+    gp.set_exchange("mesh")
+    vm = gp.lml(theta)
+    vm2, gm = gp.lml_grad(theta)
+    assert vm == val and vm2 == val and np.array_equal(gm, g), (rank, N, vm, val)
+    gp.set_option(5, 0)
+    assert abs(gp.lml(theta) - val) <= 1e-11 * abs(val)
+    gp.set_option(5, 2)
+    gp.set_exchange("bcast")
+    assert gp.lml(theta) == val
 vals = parallel.gather_objects(out)
 assert all(v == vals[0] for v in vals), vals  # every rank holds the same all-reduced LML
 if rank == 0:

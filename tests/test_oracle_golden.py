@@ -153,3 +153,25 @@ def test_data_gradients_match_mpmath_golden():
         dvar_ref = np.array([float(v) for v in c["dvar"]])
         assert np.abs(dmu[0] - dmu_ref).max() <= 10 * tol * max(np.abs(dmu_ref).max(), 1e-300), c["name"]
         assert np.abs(dvar[0] - dvar_ref).max() <= 10 * tol * max(np.abs(dvar_ref).max(), 1e-300), c["name"]
+
+
+def _illcond_truth(c):
+    """(theta, lml, gradient in C-ABI positions, their indices, cond) of an ill-conditioned golden case."""
+    nk, d = len(c["kerns"]), c["d"]
+    theta = case_theta(c)
+    idx = list(range(nk * d)) + [nk * d + k for k in range(nk)] + [nk * d + 2 * nk]  # ls, kv, gv
+    K = orc.noisy_cov(np.array(c["X"]), c["kerns"], c["ops"], theta)
+    return theta, float(c["lml"]), np.array([float(v) for v in c["grad"]]), idx, np.linalg.cond(K)
+
+
+def test_oracle_in_the_ill_conditioned_regime_vs_mpmath():
+    """cond(K) 2e7 .. 8e8 (oracle/gen_golden_illcond.py): the NumPy oracle's forward error against the 50-digit truth stays
+    within a few cond * eps -- the yardstick the GPU test measures the device against."""
+    eps = np.finfo(float).eps
+    for c in load_json("mpmath_illcond.json"):
+        theta, lml, grad, idx, cond = _illcond_truth(c)
+        assert 1e7 <= cond <= 1e9, (c["name"], cond)
+        val, g = orc.lml_grad(np.array(c["X"]), np.array(c["y"]), c["kerns"], c["ops"], theta)
+        assert abs(val - lml) <= 8 * cond * eps * max(abs(lml), 1.0), (c["name"], val, lml)
+        err = np.abs(g[idx] - grad).max() / np.abs(grad).max()
+        assert err <= 8 * cond * eps, (c["name"], err / (cond * eps))

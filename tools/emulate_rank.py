@@ -78,7 +78,7 @@ def run_rank(X, y, kernel, theta, world, rank, pwt, source, reps=2, options=None
     return rec
 
 
-def predict(world, recs, N, pwt, serial, link_gbps=LINK_GBPS, pipelined=True):
+def predict(world, recs, N, pwt, serial, link_gbps=LINK_GBPS, pipelined=True, exchange="bcast"):
     """Timeline of a `world`-rank evaluation from the emulated ranks' per-step times (a model, not a measurement).
     Rank r at step j starts when panel j has arrived and its own previous work is done.  The owner of panel j + 1 runs
     its chain (update + factor + stage) -- ahead of its bulk update (serial: option 3 = 1) or beside it on the side
@@ -117,6 +117,10 @@ def predict(world, recs, N, pwt, serial, link_gbps=LINK_GBPS, pipelined=True):
         ready[:] = 1.0
     wj = np.array([min(pwt, (npad // 128) - j * pwt) for j in range(npan + 1)])
     piece_ms = np.array([(npad + 128 - j * pw + 128) * 128 * 8 / (link_gbps * 1e9) * 1e3 for j in range(npan + 1)])
+    if exchange == "mesh" and world > 2:
+        # DistGP.set_exchange("mesh"): the owner sends 1 / (W - 1) of a piece to every peer over that peer's own link, then the
+        # peers all-gather among themselves over theirs: two transfers of bytes / (W - 1) per link instead of one of `bytes`
+        piece_ms *= 2.0 / (world - 1)
     link = piece_ms * np.maximum(wj, 0)
     if world == 1:
         link[:] = 0.0
@@ -153,7 +157,7 @@ def predict(world, recs, N, pwt, serial, link_gbps=LINK_GBPS, pipelined=True):
             "predicted_ms": float(free.max()), "sum_bulk_ms_slowest_rank": float(max(b.sum() for b in bulk)),
             "sum_chain_ms": float(chain[:npan].sum()), "sum_link_ms": float(link[:npan].sum()),
             "sum_link_ms_behind_the_chain": float(exposed),
-            "link_GBps_assumed": link_gbps, "ranks_emulated": emu}
+            "link_GBps_assumed": link_gbps, "exchange": exchange, "ranks_emulated": emu}
 
 
 def main():
@@ -166,6 +170,8 @@ def main():
     ap.add_argument("--panel-tiles", type=int, default=0)
     ap.add_argument("--curve", action="store_true")
     ap.add_argument("--opt", action="append", default=[], help="shard option id=value (repeatable)")
+    ap.add_argument("--links", default="153,77", help="one-way GB/s per xGMI link to model (AMD quotes 153.6 GB/s per link, "
+                    "most likely bidirectional: 77 one way)")
     ap.add_argument("--out", default="gpurun_out/sharded_model.json")
     args = ap.parse_args()
 
@@ -198,12 +204,14 @@ def main():
                 assert abs(ld_sum - logdet) <= 1e-10 * abs(logdet) and abs(q_sum - quad) <= 1e-9 * abs(quad), (ld_sum, logdet, q_sum, quad)
                 print(f"partial sums of all {world} ranks reproduce the single-GPU log-det and quadratic form", flush=True)
             for pipelined in ([True, False] if (serial and world > 1) else [False]):
-                pred = predict(world, recs, N, pwt, bool(serial), pipelined=pipelined)
-                pred["panel_tiles"] = pwt
-                pred["speedup_vs_single_gpu_path"] = single_ms / pred["predicted_ms"]
-                pred["compute_ms_x_world_over_single"] = max(r["bulk_ms"] + r["update_ms"] + r["factor_ms"] for r in recs) * world / single_ms
-                print(json.dumps(pred), flush=True)
-                out["prediction"].append(pred)
+                for link in ([float(v) for v in args.links.split(",")] if world > 1 else [LINK_GBPS]):
+                    for exchange in (["bcast", "mesh"] if world > 2 else ["bcast"]):
+                        pred = predict(world, recs, N, pwt, bool(serial), link_gbps=link, pipelined=pipelined, exchange=exchange)
+                        pred["panel_tiles"] = pwt
+                        pred["speedup_vs_single_gpu_path"] = single_ms / pred["predicted_ms"]
+                        pred["compute_ms_x_world_over_single"] = max(r["bulk_ms"] + r["update_ms"] + r["factor_ms"] for r in recs) * world / single_ms
+                        print(json.dumps(pred), flush=True)
+                        out["prediction"].append(pred)
             out["runs"] += [{k: v for k, v in r.items() if k not in ("steps", "pieces")} for r in recs]
             os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
             json.dump(out, open(args.out, "w"), indent=1)

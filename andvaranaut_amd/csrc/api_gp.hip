@@ -37,6 +37,7 @@ struct mi_gp_handle {
   bool smo_supported;               // hipDeviceAttributeCanUseStreamWaitValue
   int poll_limit_log2;              // option 27: an in-kernel poll gives up after 2^this sleeps (default 22: seconds)
   int test_drop_signal;             // option 28 (tests): the next evaluation leaves one main-stream signal unwritten
+  int a2_low;                       // option 29: the main stream's next-panel update (a2) runs one workgroup per CU (default 0)
   int use_smo;                      // option 26: 0 events, 1 runtime stream memory operations, 2 (default) the panel stream's
                                     // halves folded into one-lane launches of the library / the end of a leaf
   // tuning options (mi_gp_set_option), all per handle
@@ -198,6 +199,7 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   }
   h->poll_limit_log2 = 22;
   h->test_drop_signal = 0;
+  h->a2_low = 0;
   h->sig_epoch = 0;
   h->sig_next = 0;
   h->wait_slot = -1;
@@ -274,6 +276,7 @@ extern "C" int mi_gp_set_option(mi_gp_handle* h, int what, int value) {
   else if (what == 26) h->use_smo = !h->smo_supported ? 0 : value < 0 ? 0 : value > 2 ? 2 : value;
   else if (what == 27) h->poll_limit_log2 = value < 4 ? 4 : value > 30 ? 30 : value;
   else if (what == 28) h->test_drop_signal = value ? 1 : 0;
+  else if (what == 29) h->a2_low = value ? 1 : 0;
   else if (what == 9) h->tail_small = value ? 1 : 0;
   else {
     snprintf(h->err, sizeof(h->err), "mi_gp_set_option: unknown option %d", what);
@@ -562,7 +565,11 @@ static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int nt
       }
       CKE(syrk_trapezoid(h, A, lda, ntr, n1, 1, J, w, P));
       if (wn > 1) {
-        CKE(syrk_trapezoid(h, A, lda, ntr, n1 + 1, wn - 1, J, w, T));
+        // (option 29 = 1 runs it one workgroup per CU: the chain's next leaf needs a CU to itself, and with two 64x64-tile
+        // workgroups on every CU none empties before this grid drains -- the first leaf of a super-panel waits 70-160 us at
+        // N = 8192.  Measured: the update itself then takes so much longer that N >= 8192 loses 1.5-2 % (the chain waits for
+        // THIS launch at those steps, not for the leaf) and N <= 6144 gains under 1 %: off by default.)
+        CKE(syrk_trapezoid(h, A, lda, ntr, n1 + 1, wn - 1, J, w, T, h->a2_low));
         if (h->test_drop_signal && h->use_smo && h->sig_next < SIG_SLOTS) {
           // test hook (option 28): this edge's slot is never written -- the panel stream's poll has to give up
           h->test_drop_signal = 0;

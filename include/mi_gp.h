@@ -164,6 +164,7 @@ int mi_gp_predict_grad(mi_gp_handle* h, const double* Xnew_dev, int m, double* w
  *      handles evaluating concurrently per device with mode 2 (tests run six), or use mode 0 / 1 beyond that.
  *   27 log2 of the number of sleeps after which such a poll gives up (default 22 = seconds; 4 .. 30)
  *   28 test hook: the next two-stream evaluation leaves one main-stream signal unwritten (its poll must give up)
+ *   29 the main stream's update of the next super-panel's columns 2.. runs one workgroup per CU (default 0; scheduling only)
  * 8, 14, 16, 18, 19, 21, 24, 26 and 27 only change scheduling (bit-identical results); 20 moves tiles between the two GEMM kernels (same k order); 2, 4-7, 9 regroup sums (agreement to rounding), and so does 0 where
  * it changes the super-panel width (20 to 60 tile columns).
  * Unknown ids return -1.  (Round 1's options 1, 3, 10-13 -- GEMM variants, hipGraph replay, persistent bulk kernels,

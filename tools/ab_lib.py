@@ -1,0 +1,57 @@
+"""A/B of whole library BUILDS on one box: alternating subprocesses, one per (library, round).
+    python tools/ab_lib.py "4096 8 RBF" "8192 8 RBF" -- tools/ab/lib_a.so tools/ab/lib_b.so
+Each subprocess loads the given libmi_gp.so (andvaranaut_amd._lib.LIB_PATH), evaluates the LML a few times and prints the
+median; three rounds per library, interleaved, so that box-to-box and drift effects cancel."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+WORKER = r'''
+import os, sys, time
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import andvaranaut_amd._lib as L
+L.LIB_PATH = os.path.abspath(sys.argv[2])
+from andvaranaut_amd import MiGP
+from bench import synth_problem, theta_sequence
+N, d, kern = int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+X, y = synth_problem(N, d, seed=0)
+gp = MiGP(X, y, kern, need_grad=False)
+th = theta_sequence(d, 8, seed=0)
+for i in range(3):
+    gp.lml(th[i])
+res = []
+reps = 10 if N <= 8192 else 5
+for rnd in range(5):
+    t0 = time.perf_counter()
+    for i in range(reps):
+        v = gp.lml(th[i % 8])
+    res.append((time.perf_counter() - t0) / reps * 1e3)
+print(np.median(res), v)
+'''
+
+
+def main():
+    args = sys.argv[1:]
+    specs, libs = args[: args.index("--")], args[args.index("--") + 1:]
+    for spec in specs:
+        res = {l: [] for l in libs}
+        vals = {}
+        for rnd in range(3):
+            for l in libs:
+                out = subprocess.run([sys.executable, "-c", WORKER, ROOT, l] + spec.split(), capture_output=True, text=True)
+                if out.returncode != 0:
+                    print(out.stderr[-500:])
+                    continue
+                t, v = out.stdout.strip().splitlines()[-1].split()
+                res[l].append(float(t))
+                vals[l] = v
+        for l in libs:
+            print(f"{spec:>22s}  {os.path.basename(l):28s} median {np.median(res[l]):8.3f} ms   runs {['%.3f' % x for x in res[l]]}  value {vals.get(l)}", flush=True)
+
+
+if __name__ == "__main__":
+    main()

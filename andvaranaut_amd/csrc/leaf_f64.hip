@@ -51,7 +51,7 @@ __device__ unsigned long long g_leaf_probe_out;
 __device__ int g_leaf_probe_sel;
 #define LEAF_PROBE(code)                                                                    \
   do {                                                                                      \
-    if (probe_sel == (code) && (threadIdx.x & 63) == 0 && threadIdx.x <= 64) {              \
+    if (probe_sel == (code) && (threadIdx.x == 0 || threadIdx.x == 64 || threadIdx.x == 320)) { \
       unsigned long long t_;                                                                \
       asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");           \
       g_leaf_probe_out = t_ - t_start;                                                      \
@@ -314,9 +314,10 @@ __device__ __forceinline__ void static_for(F&& f) {
 //      up to scalings, for free.
 //  waves 1..3 (helpers): keep the 27 trailing 16x16 tiles in registers (namespace lt), left-looking.  Behind `ready` they
 //      first finish the tiles of the NEXT block column (their last update: results go to the LDS image, `urgent` is
-//      raised), then update the other live tiles while wave 0 already eliminates the next block; then, in the time they
-//      used to spin, they form block row jb of M = L^-1 from Y_jb and the rows above (see `inverse`), and normalise column
+//      raised), then update the other live tiles while wave 0 already eliminates the next block, and normalise column
 //      block jb - 1 on its way out to memory (L = X~ D^-1/2; the LDS image stays unnormalised).
+//  waves 5..7 (the inverse; wave 4 idles): beside the helpers on SIMDs 1..3, they form block row jb of M = L^-1 from Y_jb
+//      and the rows above (see `inverse`).
 // No workgroup barrier inside the loop: the sides meet through LDS counters.  The explicit inverse used to be a phase of its
 // own behind the factorisation (8 substitutions + three block-doubling levels, ~6 us of the leaf's 30); what is left behind
 // the last pivot now is one 16x16x16 product per tile of the last block row.
@@ -332,7 +333,7 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
   double* Mh = Ybuf + 4 * SB * YB_LD;   // [36][MT_ELEMS] M^ = D^-1/2 M (block row b, block column c <= b at mt_off(b, c))
   lds_int_t* sync_a = (lds_int_t*)(Mh + 36 * MT_ELEMS);
   volatile lds_int_t* sync_w = sync_a;  // [0] column blocks published by wave 0, [1] urgent
-  // arrivals of waves 1..3, [2] their load arrivals, [3] their arrivals with a block row of M^
+  // arrivals of waves 1..3, [2] their load arrivals, [3] the arrivals of the inverse's waves (5..7) with a block row of M^
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: tile coordinates and soff() bases derived
@@ -416,6 +417,11 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
         const double e0 = __builtin_fma(-my_p, y0, 1.0);
         const double nq = __builtin_fma(-e0, e0, -e0);
         my_nr = __builtin_fma(y0, nq, -y0);
+      }
+      // (the identity rows go into buffer jb & 3: the inverse's waves run on their own and have to be through with block row
+      // jb - 4, the buffer's previous user -- they always are; the check is one LDS read)
+      if (jb >= 4) {
+        while (sync_w[3] < 3 * (jb - 3)) __builtin_amdgcn_s_sleep(1);
       }
       // X~ of the rows below the block (and the identity rows), the pivots and their reciprocals first: the updates wait for
       // them; the block's own rows are read by nobody before the normalisation
@@ -510,7 +516,8 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
   } else {
     // ---------------------------------------------------------------- the helpers
     const int t = tid - 64;
-    {  // the LDS image right of column block 0: row block b holds 16 rows x 8 b pieces of 16 bytes there
+    if (wave <= 3) {  // (the helpers; the inverse's waves start at the first published block)
+      // the LDS image right of column block 0: row block b holds 16 rows x 8 b pieces of 16 bytes there
       double2_t v[21];  // sum over row blocks of ceil(128 b / 192)
       int u = 0;
 #pragma unroll
@@ -741,8 +748,6 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
     };
     auto helper = [&](auto Wc) {
       load_tiles(Wc);
-#pragma unroll
-      for (int q = 0; q < 3; ++q) tbulk[q] = (double4_t){0.0, 0.0, 0.0, 0.0};
       // fully unrolled: every copy sees a constant jb, the tile accumulators have plain live ranges (no loop-carried phis
       // through a switch: that form cost 200 registers of copies and moved the accumulators to AGPRs)
       lt::static_for<0, LEAF / SB>([&](auto JBc) {
@@ -758,18 +763,37 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
           trailing(JBc, Wc, std::integral_constant<int, 1>());
           LEAF_PROBE(64 + 8 * JB + 2);
         }
-        inv_final(JBc, Wc);
-        LEAF_PROBE(64 + 8 * JB + 3);
         if constexpr (JB >= 1) stream_out(JB - 1);
         LEAF_PROBE(64 + 8 * JB + 4);
-        inv_t(JBc, Wc);
-        LEAF_PROBE(64 + 8 * JB + 5);
       });
       // (wave 0 writes the last diagonal block of L and of M from its registers)
     };
+    // The inverse's waves: the workgroup has eight waves, and wave 5 + w shares SIMD 1 + w with helper w (the waves of a
+    // workgroup are dealt to the SIMDs round robin) -- the hardware interleaves the two instruction streams, so the inverse
+    // fills the issue slots the helper leaves and never delays an urgent tile.  (As ONE instruction stream the helpers
+    // reached the urgent phases of iterations 4 and 5 ~2k cycles late: N = 2048 0.746 -> 0.735 ms, N = 4096 1.660 -> 1.633,
+    // N = 8192 4.93 -> 4.89, same bits.)
+    auto inverse_worker = [&](auto Wc) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) tbulk[q] = (double4_t){0.0, 0.0, 0.0, 0.0};
+      lt::static_for<0, LEAF / SB>([&](auto JBc) {
+        constexpr int JB = decltype(JBc)::value;
+        while (sync_w[0] < JB + 1) __builtin_amdgcn_s_sleep(1);
+        wave_lds_fence();
+        LEAF_PROBE(128 + 8 * JB + 0);
+        inv_final(JBc, Wc);
+        LEAF_PROBE(128 + 8 * JB + 1);
+        inv_t(JBc, Wc);
+        LEAF_PROBE(128 + 8 * JB + 2);
+      });
+    };
     if (wave == 1) helper(std::integral_constant<int, 0>());
     else if (wave == 2) helper(std::integral_constant<int, 1>());
-    else helper(std::integral_constant<int, 2>());
+    else if (wave == 3) helper(std::integral_constant<int, 2>());
+    else if (wave == 5) inverse_worker(std::integral_constant<int, 0>());
+    else if (wave == 6) inverse_worker(std::integral_constant<int, 1>());
+    else if (wave == 7) inverse_worker(std::integral_constant<int, 2>());
+    // (wave 4 would share SIMD 0 with the chain: it does nothing)
   }
   LEAF_PROBE(63);
   // Last tile column of an evaluation: the only rows below are the y^T row block (one non-zero row), so the forward
@@ -780,7 +804,7 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
     double* ys = Ybuf;  // scratch
     if (tid < LEAF) ys[tid] = yrow[tid];
     __syncthreads();
-    const int c = tid >> 1, half = tid & 1;
+    const int c = (tid & 255) >> 1, half = tid & 1;  // (waves 4..7 repeat waves 0..3: same values, same addresses)
     // M[c][k] = sqrt(d_c) M^[c][k]; M^ element [i][j] of tile (b, cb) sits at mt_off(b, cb) + 64 (i >> 2) + 16 (i & 3) + j
     const int b = c >> 4, i = c & 15;
     const double* mrow = Mh + mt_off(b, 0) + 64 * (i >> 2) + 16 * (i & 3);
@@ -808,7 +832,7 @@ __device__ __forceinline__ void poll_signal(const unsigned* ptr, unsigned val, i
   }
 }
 
-__global__ __launch_bounds__(256, 1) void potrf_leaf128_kernel(double* __restrict__ Ablk, long lda,
+__global__ __launch_bounds__(512, 1) void potrf_leaf128_kernel(double* __restrict__ Ablk, long lda,
                                                                 double* __restrict__ minv, int col0,
                                                                 int* __restrict__ info, double* yrow, long sA, long sminv,
                                                                 int sinfo, const unsigned* wait_ptr, unsigned wait_val,
@@ -967,7 +991,7 @@ hipError_t leaf_enable_lds() {
 
 hipError_t launch_potrf_leaf128(double* Ablk, long lda, double* minv, int col0, int* info, hipStream_t stream, double* yrow,
                                 const Batch* bt, const unsigned* wait_ptr, unsigned wait_val, int poll_log2) {
-  potrf_leaf128_kernel<<<bt ? bt->nb : 1, 256, LEAF_LDS_BYTES, stream>>>(Ablk, lda, minv, col0, info, yrow, bt ? bt->sK : 0,
+  potrf_leaf128_kernel<<<bt ? bt->nb : 1, 512, LEAF_LDS_BYTES, stream>>>(Ablk, lda, minv, col0, info, yrow, bt ? bt->sK : 0,
                                                                         bt ? bt->sdinv : 0, bt ? bt->sinfo : 0, wait_ptr, wait_val,
                                                                         poll_log2);
   return hipGetLastError();

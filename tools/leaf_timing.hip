@@ -46,8 +46,10 @@ int main() {
   for (int jb = 0; jb < 8; ++jb) { printf("  %d:", jb); for (int k = 0; k < 6; ++k) printf(" %7llu", probe(8 * jb + k)); printf("\n"); }
   printf("wave 0 end of loop: %llu\n", probe(63));
   printf("wave 1  initial load done: %llu\n", probe(62));
-  printf("wave 1  jb: ready seen | urgent arrived | lazy done | block row of M done | stream-out issued | T of next row done\n");
-  for (int jb = 0; jb < 8; ++jb) { printf("  %d:", jb); for (int k = 0; k < 6; ++k) printf(" %7llu", probe(64 + 8 * jb + k)); printf("\n"); }
+  printf("wave 1 (helper)  jb: ready seen | urgent arrived | lazy done | stream-out issued\n");
+  for (int jb = 0; jb < 8; ++jb) { printf("  %d:", jb); for (int k : {0, 1, 2, 4}) printf(" %7llu", probe(64 + 8 * jb + k)); printf("\n"); }
+  printf("wave 5 (inverse)  jb: ready seen | block row of M done | T terms done\n");
+  for (int jb = 0; jb < 8; ++jb) { printf("  %d:", jb); for (int k = 0; k < 3; ++k) printf(" %7llu", probe(128 + 8 * jb + k)); printf("\n"); }
 #endif
   hipMemcpy(A.data(), dA, A.size() * 8, hipMemcpyDeviceToHost);
   double err = 0;

@@ -37,6 +37,11 @@ struct mi_gp_handle {
   bool smo_supported;               // hipDeviceAttributeCanUseStreamWaitValue
   int poll_limit_log2;              // option 27: an in-kernel poll gives up after 2^this sleeps (default 22: seconds)
   int test_drop_signal;             // option 28 (tests): the next evaluation leaves one main-stream signal unwritten
+  int u_early_max_s;                // option 30: block-doubling levels of U = L^-T (node sizes up to this many tiles) that start inside the
+                                    // factorisation's chain-bound tail on the main stream (gradient evaluations; 0: none)
+  int u_early_cols;                 // option 31: ... from this many trailing tile columns on, and at most this many new columns per step
+  bool u_early;                     // this evaluation takes part (set by enqueue_all)
+  int u_leaf_done, u_node_done[12]; // tile columns whose leaf block of U is done / full nodes done per level
   int a2_low;                       // option 29: the main stream's next-panel update (a2) runs one workgroup per CU (default 0)
   int use_smo;                      // option 26: 0 events, 1 runtime stream memory operations, 2 (default) the panel stream's
                                     // halves folded into one-lane launches of the library / the end of a leaf
@@ -200,6 +205,9 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   h->poll_limit_log2 = 22;
   h->test_drop_signal = 0;
   h->a2_low = 0;
+  h->u_early_max_s = 16;
+  h->u_early_cols = 48;
+  h->u_early = false;
   h->sig_epoch = 0;
   h->sig_next = 0;
   h->wait_slot = -1;
@@ -277,6 +285,8 @@ extern "C" int mi_gp_set_option(mi_gp_handle* h, int what, int value) {
   else if (what == 27) h->poll_limit_log2 = value < 4 ? 4 : value > 30 ? 30 : value;
   else if (what == 28) h->test_drop_signal = value ? 1 : 0;
   else if (what == 29) h->a2_low = value ? 1 : 0;
+  else if (what == 30) h->u_early_max_s = value < 0 ? 0 : value;
+  else if (what == 31) h->u_early_cols = value < 8 ? 8 : value;
   else if (what == 9) h->tail_small = value ? 1 : 0;
   else {
     snprintf(h->err, sizeof(h->err), "mi_gp_set_option: unknown option %d", what);
@@ -458,6 +468,8 @@ constexpr int LOOKAHEAD_MIN_TILES = 20;  // round 4: with the single-stream tail
                                        // 1.022, 2560 1.145 vs 1.119, 2816 1.268 vs 1.251, 3072 1.373 vs 1.352, 3328 1.532 vs 1.484,
                                        // 3584 1.736 vs 1.606)
 
+static hipError_t u_levels(mi_gp_handle* h, int final_cols, int max_s);
+
 static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int ntc) {
   // A batched evaluation (blockIdx.z = problem) carries nb times the work per launch, so the look-ahead pays from smaller
   // problems on (nb = 8: N = 2560 +5 %, 3072 +10 %, 4096 +7 %; nb = 2 from 3072 on).  The super-panel widths stay those of
@@ -496,6 +508,14 @@ static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int nt
     // ONE one-lane launch on the panel stream (write, then poll) instead of two runtime kernels; the main stream's halves
     // stay runtime stream memory operations.
     int tp_slot = -1;  // >= 0: the panel stream already waits for this slot; the T -> P edge below only has to write it
+    if (P != T && h->u_early && J > 0 && ntc - J <= h->u_early_cols) {
+      // Gradient evaluations: in the chain-bound last steps the main stream would now idle until the panel stream has
+      // factored super-panel J.  The leaf blocks and the first block-doubling levels of U = L^-T over the columns that are
+      // final (everything left of J) run here instead of behind the factorisation (same launches on the same tiles, only
+      // grouped differently over the node batches: same bits).
+      const int upto = h->u_leaf_done + h->u_early_cols / 2 < J ? h->u_leaf_done + h->u_early_cols / 2 : J;
+      CKE(u_levels(h, upto, h->u_early_max_s));
+    }
     if (P != T) {
       const bool stays_two = n1 < ntc && !(ntc - n1 <= h->single_below / nb);
       bool tp_edge = false;
@@ -658,6 +678,11 @@ static int enqueue_gradient(mi_gp_handle* h, bool prof);
 static hipError_t inverse_transpose(mi_gp_handle* h);
 
 static int enqueue_all(mi_gp_handle* h, int what, bool prof) {
+  h->u_leaf_done = 0;
+  for (int& v : h->u_node_done) v = 0;
+  // (from 64 tile columns on: N = 8192 LML + gradient 11.17 -> 10.98 ms, N = 16384 69.81 -> 69.40; at N = 4096 the main stream
+  // has no idle time to fill in those steps: 2.74 -> 2.81)
+  h->u_early = what == 2 && !h->btp && h->u_early_max_s > 0 && h->ntc >= 64 && h->buf.Z_dev && h->buf.W_dev;
   if (int r = enqueue_factor(h, what == 1 ? 1 : 0, prof)) return r;
   if (what == 2) return enqueue_gradient(h, prof);
   return 0;
@@ -771,6 +796,56 @@ static hipError_t gemm_call(mi_gp_handle* h, int ak, int bk, const double* A, lo
   return launch_gemm_f64(p, ak, bk, batch, h->stream);
 }
 
+// Leaf blocks and FULL nodes of the block-doubling levels of U over tile columns [0, final_cols) of L, as far as they are
+// not done yet (u_leaf_done / u_node_done): level s (nodes of 2 s tiles, li = log2 s) needs its nodes' halves -- full nodes of
+// level s / 2 -- done.  Called with growing final_cols inside the factorisation's tail (cholesky()) and once with everything
+// from inverse_transpose(); the node batches are split differently, the per-tile arithmetic is the same.
+static hipError_t u_levels(mi_gp_handle* h, int final_cols, int max_s) {
+  const double* L = h->buf.K_dev;
+  double* U = h->buf.Z_dev;
+  double* T = h->buf.W_dev;
+  const long ld = h->buf.lda;
+  const int ntc = h->ntc;
+  const long zK = h->btp ? h->btp->sK : 0, zZ = h->btp ? h->btp->sZ : 0, zW = h->btp ? h->btp->sW : 0;
+  hipError_t e;
+  if (final_cols > ntc) final_cols = ntc;
+  if (final_cols > h->u_leaf_done) {
+    if (h->u_leaf_done == 0) {
+      e = launch_set_identity_blocks(U, ld, ntc, h->stream, h->btp);
+      if (e != hipSuccess) return e;
+    }
+    // leaves: X L_kk^T = I  ->  X = L_kk^-T
+    const int c0 = h->u_leaf_done;
+    e = launch_trsm_strip128_batched(h->dinv_dev + (size_t)c0 * MINV_ELEMS, U + (long)c0 * (128 * ld + 128), ld, 128 * ld + 128, 128,
+                                     final_cols - c0, h->stream, h->btp, zZ);
+    if (e != hipSuccess) return e;
+    h->u_leaf_done = final_cols;
+  }
+  int li = 0;
+  for (int s = 1; s < ntc && s <= max_s; s *= 2, ++li) {
+    const int child_cols = li == 0 ? h->u_leaf_done : h->u_node_done[li - 1] * s;  // columns covered by finished halves
+    const int avail = child_cols / (2 * s);  // (<= ntc / (2 s): only full nodes)
+    const int done = h->u_node_done[li];
+    if (avail <= done) continue;
+    const long node = (long)2 * s * 128 * (ld + 1);
+    const long off = (long)done * node;
+    const int batch = avail - done;
+    const double* U11 = U + off;
+    const double* U22 = U + off + (long)s * 128 * (ld + 1);
+    const double* L21 = L + off + (long)s * 128 * ld;
+    double* P = T + off + (long)s * 128;
+    double* U12 = U + off + (long)s * 128;
+    // P = U11 L21^T   (U11 upper triangular: k >= row tile)
+    e = gemm_call(h, 0, 0, U11, ld, node, L21, ld, node, P, ld, node, s, s, s * 128, 0, 3, 1.0, 0.0, batch, zZ, zK, zW);
+    if (e != hipSuccess) return e;
+    // U12 = -P U22    (U22 upper triangular: k <= column tile)
+    e = gemm_call(h, 0, 1, P, ld, node, U22, ld, node, U12, ld, node, s, s, s * 128, 0, 4, -1.0, 0.0, batch, zW, zZ, zZ);
+    if (e != hipSuccess) return e;
+    h->u_node_done[li] = avail;
+  }
+  return hipSuccess;
+}
+
 static hipError_t inverse_transpose(mi_gp_handle* h) {
   const double* L = h->buf.K_dev;
   double* U = h->buf.Z_dev;
@@ -778,33 +853,27 @@ static hipError_t inverse_transpose(mi_gp_handle* h) {
   const long ld = h->buf.lda;
   const int ntc = h->ntc;
   const long zK = h->btp ? h->btp->sK : 0, zZ = h->btp ? h->btp->sZ : 0, zW = h->btp ? h->btp->sW : 0;
-  hipError_t e = launch_set_identity_blocks(U, ld, ntc, h->stream, h->btp);
-  if (e != hipSuccess) return e;
-  // leaves: X L_kk^T = I  ->  X = L_kk^-T
-  e = launch_trsm_strip128_batched(h->dinv_dev, U, ld, 128 * ld + 128, 128, ntc, h->stream, h->btp, zZ);
+  // every full node of every level (what the factorisation's tail has not done already), then the trailing partial nodes
+  // level by level: a partial node's first half is a full node of the level below, its second half is built by the partial
+  // nodes of the levels below
+  hipError_t e = u_levels(h, ntc, 1 << 30);
   if (e != hipSuccess) return e;
   for (int s = 1; s < ntc; s *= 2) {
     const int nfull = ntc / (2 * s);             // nodes whose second half is complete
     const int rem = ntc - nfull * 2 * s;         // tiles left for a trailing partial node
+    if (rem <= s) continue;
     const long node = (long)2 * s * 128 * (ld + 1);
-    for (int pass = 0; pass < 2; ++pass) {
-      int batch, s2;
-      long off;
-      if (pass == 0) { batch = nfull; s2 = s; off = 0; }
-      else { batch = (rem > s) ? 1 : 0; s2 = rem - s; off = (long)nfull * node; }
-      if (batch == 0) continue;
-      const double* U11 = U + off;
-      const double* U22 = U + off + (long)s * 128 * (ld + 1);
-      const double* L21 = L + off + (long)s * 128 * ld;
-      double* P = T + off + (long)s * 128;
-      double* U12 = U + off + (long)s * 128;
-      // P = U11 L21^T   (U11 upper triangular: k >= row tile)
-      e = gemm_call(h, 0, 0, U11, ld, node, L21, ld, node, P, ld, node, s, s2, s * 128, 0, 3, 1.0, 0.0, batch, zZ, zK, zW);
-      if (e != hipSuccess) return e;
-      // U12 = -P U22    (U22 upper triangular: k <= column tile)
-      e = gemm_call(h, 0, 1, P, ld, node, U22, ld, node, U12, ld, node, s, s2, s2 * 128, 0, 4, -1.0, 0.0, batch, zW, zZ, zZ);
-      if (e != hipSuccess) return e;
-    }
+    const int s2 = rem - s;
+    const long off = (long)nfull * node;
+    const double* U11 = U + off;
+    const double* U22 = U + off + (long)s * 128 * (ld + 1);
+    const double* L21 = L + off + (long)s * 128 * ld;
+    double* P = T + off + (long)s * 128;
+    double* U12 = U + off + (long)s * 128;
+    e = gemm_call(h, 0, 0, U11, ld, node, L21, ld, node, P, ld, node, s, s2, s * 128, 0, 3, 1.0, 0.0, 1, zZ, zK, zW);
+    if (e != hipSuccess) return e;
+    e = gemm_call(h, 0, 1, P, ld, node, U22, ld, node, U12, ld, node, s, s2, s2 * 128, 0, 4, -1.0, 0.0, 1, zW, zZ, zZ);
+    if (e != hipSuccess) return e;
   }
   return hipSuccess;
 }

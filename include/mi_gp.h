@@ -165,7 +165,11 @@ int mi_gp_predict_grad(mi_gp_handle* h, const double* Xnew_dev, int m, double* w
  *   27 log2 of the number of sleeps after which such a poll gives up (default 22 = seconds; 4 .. 30)
  *   28 test hook: the next two-stream evaluation leaves one main-stream signal unwritten (its poll must give up)
  *   29 the main stream's update of the next super-panel's columns 2.. runs one workgroup per CU (default 0; scheduling only)
- * 8, 14, 16, 18, 19, 21, 24, 26 and 27 only change scheduling (bit-identical results); 20 moves tiles between the two GEMM kernels (same k order); 2, 4-7, 9 regroup sums (agreement to rounding), and so does 0 where
+ *   30 gradient evaluations of 64 tile columns and more: the leaf blocks and the block-doubling levels of U = L^-T with nodes of
+ *      up to this many tiles start on the main stream inside the factorisation's chain-bound last steps instead of behind it
+ *      (default 16, 0: never; same launches per tile, bit-identical gradients; N = 16384 LML + gradient 69.8 -> 69.4 ms)
+ *   31 ... in the steps with at most this many trailing tile columns, half as many new columns per step (default 48)
+ * 8, 14, 16, 18, 19, 21, 24, 26, 27, 29, 30 and 31 only change scheduling (bit-identical results); 20 moves tiles between the two GEMM kernels (same k order); 2, 4-7, 9 regroup sums (agreement to rounding), and so does 0 where
  * it changes the super-panel width (20 to 60 tile columns).
  * Unknown ids return -1.  (Round 1's options 1, 3, 10-13 -- GEMM variants, hipGraph replay, persistent bulk kernels,
  * exclusive leaf, fused leaf + strip -- are gone with the code they selected.) */

@@ -105,3 +105,25 @@ def test_assembly_split_follows_the_first_super_panel_width():
     ref = orc.lml(X, y, ["RBF"], [], theta)
     assert abs(a - ref) <= 1e-10 * abs(ref)
     gp.close()
+
+
+def test_early_inverse_levels_leave_the_gradient_bit_identical():
+    """Option 30: the first block-doubling levels of U = L^-T run inside the factorisation's tail on the main stream
+    (LML + gradient from 64 tile columns on) -- same launches per tile, regrouped over node batches: same bits."""
+    MiGP, orc = _mods()
+    N, d = 8320, 8  # 65 tile columns: a ragged last tile and a trailing partial node on every level
+    X, y = orc.synth_problem(N, d, seed=21)
+    theta = orc.synth_theta(d)
+    gp = MiGP(X, y, "RBF")
+    gp.set_option(30, 0)
+    v0, g0 = gp.lml_grad(theta)
+    for ms, cols in ((16, 48), (64, 48), (4, 16)):
+        gp.set_option(30, ms)
+        gp.set_option(31, cols)
+        v, g = gp.lml_grad(theta)
+        assert v == v0 and np.array_equal(g, g0), (ms, cols)
+    # ... and the conditional through U (mi_gp_predict_u forms U behind mi_gp_factor: nothing was done early there)
+    mu, var = gp.predict(theta, X[:300], via_inverse=True)
+    mu2, var2 = gp.predict(theta, X[:300], via_inverse=False)
+    assert np.allclose(mu, mu2, rtol=1e-7, atol=1e-8) and np.allclose(var, var2, rtol=1e-6, atol=1e-9)
+    gp.close()

@@ -41,7 +41,10 @@ def test_config1_map_fit_matches_oracle_backed_map_and_predicts():
     yp, yv = g.predict(xt, return_var=True)
     rmse = np.sqrt(np.mean((yp - yt) ** 2))
     r2 = 1 - np.sum((yp - yt) ** 2) / np.sum((yt - yt.mean()) ** 2)
-    assert rmse < 2e-3 and r2 > 0.9999, (rmse, r2)
+    # Measured (round 5, this seed, N = 100): RMSE 2.7e-4; N = 128 with seeds 1-3: 1.8e-4 .. 2.4e-4 -- the notebook's 1.4e-4 is
+    # on its own unseeded sample, tested at points drawn like the training points, while these 50 test points are uniform
+    # over the whole box (x2's prior is normal: the box corners are extrapolation).  Bound: 1.5 x the measured value.
+    assert rmse < 4e-4 and r2 > 0.99999, (rmse, r2)
     assert yp.shape == (50, 1) and yv.shape == (50, 1) and np.all(yv > -1e-9)
     # converted-space prediction agrees with the oracle's conditional at the fitted hypers
     theta = g._theta_from_hypers(g.hypers, 1e-6)

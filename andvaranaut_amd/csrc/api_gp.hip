@@ -42,7 +42,7 @@ struct mi_gp_handle {
   int u_early_cols;                 // option 31: ... from this many trailing tile columns on, and at most this many new columns per step
   bool u_early;                     // this evaluation takes part (set by enqueue_all)
   int u_leaf_done, u_node_done[12]; // tile columns whose leaf block of U is done / full nodes done per level
-  int a2_low;                       // option 29: the main stream's next-panel update (a2) runs one workgroup per CU (default 0)
+  int a2_low;                       // option 29: the main stream's next-panel update (a2) runs one workgroup per CU (-1, the default: up to 48 tile columns)
   int use_smo;                      // option 26: 0 events, 1 runtime stream memory operations, 2 (default) the panel stream's
                                     // halves folded into one-lane launches of the library / the end of a leaf
   // tuning options (mi_gp_set_option), all per handle
@@ -204,7 +204,7 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   }
   h->poll_limit_log2 = 22;
   h->test_drop_signal = 0;
-  h->a2_low = 0;
+  h->a2_low = -1;
   h->u_early_max_s = 16;
   h->u_early_cols = 48;
   h->u_early = false;
@@ -284,7 +284,7 @@ extern "C" int mi_gp_set_option(mi_gp_handle* h, int what, int value) {
   else if (what == 26) h->use_smo = !h->smo_supported ? 0 : value < 0 ? 0 : value > 2 ? 2 : value;
   else if (what == 27) h->poll_limit_log2 = value < 4 ? 4 : value > 30 ? 30 : value;
   else if (what == 28) h->test_drop_signal = value ? 1 : 0;
-  else if (what == 29) h->a2_low = value ? 1 : 0;
+  else if (what == 29) h->a2_low = value < 0 ? -1 : value ? 1 : 0;
   else if (what == 30) h->u_early_max_s = value < 0 ? 0 : value;
   else if (what == 31) h->u_early_cols = value < 8 ? 8 : value;
   else if (what == 9) h->tail_small = value ? 1 : 0;
@@ -588,8 +588,8 @@ static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int nt
         // (option 29 = 1 runs it one workgroup per CU: the chain's next leaf needs a CU to itself, and with two 64x64-tile
         // workgroups on every CU none empties before this grid drains -- the first leaf of a super-panel waits 70-160 us at
         // N = 8192.  Measured: the update itself then takes so much longer that N >= 8192 loses 1.5-2 % (the chain waits for
-        // THIS launch at those steps, not for the leaf) and N <= 6144 gains under 1 %: off by default.)
-        CKE(syrk_trapezoid(h, A, lda, ntr, n1 + 1, wn - 1, J, w, T, h->a2_low));
+        // THIS launch at those steps, not for the leaf) and N <= 6144 gains 0.7-1 %: by default on up to 48 tile columns.)
+        CKE(syrk_trapezoid(h, A, lda, ntr, n1 + 1, wn - 1, J, w, T, h->a2_low < 0 ? (ntc <= 48 ? 1 : 0) : h->a2_low));
         if (h->test_drop_signal && h->use_smo && h->sig_next < SIG_SLOTS) {
           // test hook (option 28): this edge's slot is never written -- the panel stream's poll has to give up
           h->test_drop_signal = 0;

@@ -752,7 +752,7 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
       // through a switch: that form cost 200 registers of copies and moved the accumulators to AGPRs)
       lt::static_for<0, LEAF / SB>([&](auto JBc) {
         constexpr int JB = decltype(JBc)::value;
-        while (sync_w[0] < JB + 1) {}
+        while (sync_w[0] < JB + 1) __builtin_amdgcn_s_sleep(1);  // (a tight spin takes issue slots from the inverse wave on this SIMD)
         wave_lds_fence();
         LEAF_PROBE(64 + 8 * JB + 0);
         if constexpr (JB <= 5) {

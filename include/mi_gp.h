@@ -164,7 +164,8 @@ int mi_gp_predict_grad(mi_gp_handle* h, const double* Xnew_dev, int m, double* w
  *      handles evaluating concurrently per device with mode 2 (tests run six), or use mode 0 / 1 beyond that.
  *   27 log2 of the number of sleeps after which such a poll gives up (default 22 = seconds; 4 .. 30)
  *   28 test hook: the next two-stream evaluation leaves one main-stream signal unwritten (its poll must give up)
- *   29 the main stream's update of the next super-panel's columns 2.. runs one workgroup per CU (default 0; scheduling only)
+ *   29 the main stream's update of the next super-panel's columns 2.. runs one workgroup per CU: 0 never, 1 always, -1 (default)
+ *      for problems of up to 48 tile columns (N = 4096 1.640 -> 1.629 ms, 6144 2.833 -> 2.806; N >= 8192 loses 1.5-2 %); scheduling only
  *   30 gradient evaluations of 64 tile columns and more: the leaf blocks and the block-doubling levels of U = L^-T with nodes of
  *      up to this many tiles start on the main stream inside the factorisation's chain-bound last steps instead of behind it
  *      (default 16, 0: never; same launches per tile, bit-identical gradients; N = 16384 LML + gradient 69.8 -> 69.4 ms)

@@ -34,6 +34,9 @@ struct mi_gp_handle {
   unsigned sig_epoch;
   int sig_next;
   int wait_slot;                    // the slot that stands in for wait_ev
+  int wait2_col, wait2_slot;        // the leaf of tile column wait2_col ends only once this slot is written (everything queued on the
+                                    // main stream before the super-panel's chain: the first in-panel update behind that leaf writes
+                                    // the next super-panel's first column), -1: none
   bool smo_supported;               // hipDeviceAttributeCanUseStreamWaitValue
   int poll_limit_log2;              // option 27: an in-kernel poll gives up after 2^this sleeps (default 22: seconds)
   int test_drop_signal;             // option 28 (tests): the next evaluation leaves one main-stream signal unwritten
@@ -42,6 +45,12 @@ struct mi_gp_handle {
   int u_early_cols;                 // option 31: ... from this many trailing tile columns on, and at most this many new columns per step
   bool u_early;                     // this evaluation takes part (set by enqueue_all)
   int u_leaf_done, u_node_done[12]; // tile columns whose leaf block of U is done / full nodes done per level
+  int thin_max_wg;                  // option 32: in-panel updates of at most this many 16-row x 128-column slices (and at most thin_max_cols
+                                    // tile columns, k <= thin_max_k) run on the thin direct-operand kernel (thin_f64.hip); 0: never
+  int thin_max_cols, thin_max_k;    // options 33 / 34
+  int ext_rows;                     // option 35: a super-panel with at most this many tile rows below it also applies its updates to
+                                    // the NEXT super-panel's first tile column, level by level (chol_panel's nx); 0: never
+  int done_col, done_slot;          // the update behind the strip of tile column done_col raises this slot ("super-panel done")
   int a2_low;                       // option 29: the main stream's next-panel update (a2) runs one workgroup per CU (-1, the default: up to 48 tile columns)
   int use_smo;                      // option 26: 0 events, 1 runtime stream memory operations, 2 (default) the panel stream's
                                     // halves folded into one-lane launches of the library / the end of a leaf
@@ -205,12 +214,18 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   h->poll_limit_log2 = 22;
   h->test_drop_signal = 0;
   h->a2_low = -1;
+  h->thin_max_wg = 256;
+  h->thin_max_cols = 2;
+  h->thin_max_k = 128;
+  h->ext_rows = 32;
+  h->done_col = h->done_slot = -1;
   h->u_early_max_s = 16;
   h->u_early_cols = 48;
   h->u_early = false;
   h->sig_epoch = 0;
   h->sig_next = 0;
   h->wait_slot = -1;
+  h->wait2_col = h->wait2_slot = -1;
   // round-2 A/B (tools/dev_ab_opts.py, interleaved in one process): bulk updates at one workgroup per CU whenever the
   // panel chain runs beside them (N = 16384: 29.99 -> 28.97 ms) and 8-tile super-panels at every size (N = 2048 1.045 ->
   // 1.017 ms, 4096 2.470 -> 2.388, 8192 6.417 -> 6.348, 16384 28.59 -> 28.39 against the 8 / 4 split of round 1)
@@ -287,6 +302,10 @@ extern "C" int mi_gp_set_option(mi_gp_handle* h, int what, int value) {
   else if (what == 29) h->a2_low = value < 0 ? -1 : value ? 1 : 0;
   else if (what == 30) h->u_early_max_s = value < 0 ? 0 : value;
   else if (what == 31) h->u_early_cols = value < 8 ? 8 : value;
+  else if (what == 32) h->thin_max_wg = value < 0 ? 0 : value;
+  else if (what == 33) h->thin_max_cols = value < 1 ? 1 : value;
+  else if (what == 34) h->thin_max_k = value;
+  else if (what == 35) h->ext_rows = value < 0 ? 0 : value;
   else if (what == 9) h->tail_small = value ? 1 : 0;
   else {
     snprintf(h->err, sizeof(h->err), "mi_gp_set_option: unknown option %d", what);
@@ -340,8 +359,24 @@ static hipError_t prof_gemm(mi_gp_handle* h, const GemmParams& p, int ak, int bk
 }
 
 // trapezoid update  A[r0:, c0:c0+nc] -= P P_c^T  with P = A[r0:, k0:k0+kw] (tile units)
+// In-panel updates only (their shapes do not depend on the schedule), by SHAPE alone -- not the batch size, not a scheduling
+// option: a batch returns the single evaluation's bits, and so does every schedule.
+static bool thin_shape(const mi_gp_handle* h, int mt, int nc, int kw) {
+  return h->thin_max_wg > 0 && nc <= h->thin_max_cols && kw * 128 <= h->thin_max_k && syrk_thin_supported(kw * 128) &&
+         (long)mt * 8 * nc <= h->thin_max_wg;
+}
+
+// wr (in-panel updates only): raised to the evaluation's epoch once everything queued on `st` before this update is done
 static hipError_t syrk_trapezoid(mi_gp_handle* h, double* A, long lda, int ntr, int r0, int nc, int k0, int kw,
-                                 hipStream_t st, int one_per_cu = 0, int tile0 = 0, int tile_cnt = 0, int fc = 0) {
+                                 hipStream_t st, int one_per_cu = 0, int tile0 = 0, int tile_cnt = 0, int fc = 0,
+                                 bool in_panel = false, unsigned* wr = nullptr) {
+  if (in_panel && thin_shape(h, ntr - r0, nc, kw))
+    return launch_syrk_thin(A + (long)r0 * 128 * lda + (long)k0 * 128, A + (long)r0 * 128 * lda + (long)r0 * 128, lda, ntr - r0, nc,
+                            kw * 128, st, h->btp, wr, h->sig_epoch);
+  if (wr != nullptr) {  // (the 64x64-tile kernel has no such hook: a one-lane launch in front of it)
+    hipError_t we = launch_signal_write_wait(wr, nullptr, h->sig_epoch, h->info_dev, st);
+    if (we != hipSuccess) return we;
+  }
   GemmParams p;
   p.one_per_cu = one_per_cu;
   p.tile0 = tile0;
@@ -371,8 +406,9 @@ static hipError_t syrk_trapezoid(mi_gp_handle* h, double* A, long lda, int ntr, 
   return prof_gemm(h, p, 0, 0, h->btp ? h->btp->nb : 1, flops, st);
 }
 
-// factor tile columns [c0, c0+w) of the (ntr x ntc)-tile trapezoid, recursively halving w
-static hipError_t chol_panel(mi_gp_handle* h, double* A, long lda, int ntr, int c0, int w, hipStream_t st) {
+// factor tile columns [c0, c0+w) of the (ntr x ntc)-tile trapezoid, recursively halving w; nx (0 / 1): every level's update
+// also covers the nx tile columns behind the panel, so that they are up to date when the panel's last strip is.
+static hipError_t chol_panel(mi_gp_handle* h, double* A, long lda, int ntr, int c0, int w, hipStream_t st, int nx = 0) {
   hipError_t e;
   if (w == 1) {
     double* blk = A + (long)c0 * 128 * lda + (long)c0 * 128;
@@ -384,9 +420,14 @@ static hipError_t chol_panel(mi_gp_handle* h, double* A, long lda, int ntr, int 
     // behind this column's strip.  Option 26 = 2: this leaf polls for that update's signal before it ends (it is done by
     // then as a rule: it started with (a1)); otherwise a runtime wait behind the strip.
     const bool waits = c0 == h->wait_col;
-    const bool folded = waits && h->wait_slot >= 0 && h->use_smo >= 2;
+    // the other edge a leaf may carry: everything the main stream had queued before this panel's chain (wait2; see cholesky()).
+    // That slot is written behind the (a2) signal, so where both fall on one leaf it stands for both.
+    const bool waits2 = c0 == h->wait2_col && h->wait2_slot >= 0 && h->use_smo >= 2;
+    const bool folded = waits2 || (waits && h->wait_slot >= 0 && h->use_smo >= 2);
+    if (c0 == h->wait2_col) h->wait2_col = -1;
     e = launch_potrf_leaf128(blk, lda, dinv, c0 * 128, h->info_dev, st, m == 128 ? blk + 128 * lda : nullptr, h->btp,
-                             folded ? h->sig_dev + h->wait_slot : nullptr, h->sig_epoch, h->poll_limit_log2);
+                             waits2 ? h->sig_dev + h->wait2_slot : folded ? h->sig_dev + h->wait_slot : nullptr, h->sig_epoch,
+                             h->poll_limit_log2);
     if (e == hipSuccess && m > 128) e = launch_trsm_strip128(dinv, blk + 128 * lda, lda, m, st, h->btp, h->btp ? h->btp->sK : 0);
     if (e == hipSuccess && waits) {
       h->wait_col = -1;
@@ -394,14 +435,20 @@ static hipError_t chol_panel(mi_gp_handle* h, double* A, long lda, int ntr, int 
         e = h->wait_slot >= 0 ? hipStreamWaitValue32(st, h->sig_dev + h->wait_slot, h->sig_epoch, hipStreamWaitValueGte, 0xffffffffu)
                               : hipStreamWaitEvent(st, h->wait_ev, 0);
     }
+    if (e == hipSuccess && nx > 0) {
+      unsigned* wr = nullptr;
+      if (c0 == h->done_col && h->done_slot >= 0) wr = h->sig_dev + h->done_slot;
+      if (c0 == h->done_col) h->done_col = -1;
+      e = syrk_trapezoid(h, A, lda, ntr, c0 + 1, nx, c0, 1, st, 0, 0, 0, 0, true, wr);
+    }
     return e;
   }
   const int w1 = w / 2, w2 = w - w1;
   e = chol_panel(h, A, lda, ntr, c0, w1, st);
   if (e != hipSuccess) return e;
-  e = syrk_trapezoid(h, A, lda, ntr, c0 + w1, w2, c0, w1, st);
+  e = syrk_trapezoid(h, A, lda, ntr, c0 + w1, w2 + nx, c0, w1, st, 0, 0, 0, 0, true);
   if (e != hipSuccess) return e;
-  return chol_panel(h, A, lda, ntr, c0 + w1, w2, st);
+  return chol_panel(h, A, lda, ntr, c0 + w1, w2, st, nx);
 }
 
 // Right-looking blocked Cholesky of the (ntr x ntc)-tile lower trapezoid with one super-panel of
@@ -484,6 +531,7 @@ static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int nt
   h->wait_col = -1;
   h->sig_next = 0;
   h->wait_slot = -1;
+  h->wait2_col = h->wait2_slot = -1;
   if (++h->sig_epoch == 0xffffffffu) {  // (4e9 factorisations on one handle: start over)
     CKE(hipStreamSynchronize(h->stream));
     CKE(hipStreamSynchronize(h->pstream));
@@ -499,7 +547,41 @@ static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int nt
   h->asm_ev_valid = false;
   const int wcap = (la_single && ntc <= NARROW_PANELS_MAX_TILES) ? 4 : 0;
   int w = pick_w(h, ntc, wcap);
-  CKE(chol_panel(h, A, lda, ntr, 0, w, P));
+  // EXTENDED super-panels (round 5, option 35): in the chain-bound part of a factorisation the panel's own in-panel updates
+  // also cover the next super-panel's first tile column (chol_panel's nx = 1), level by level.  The separate update of that
+  // column behind the panel ((a1): k = the panel's width, 23-33 us on the chain at N = 4096, and a one-lane launch for the
+  // two edges in front of it, 8 us) becomes one k = 128 update behind the last strip, whose first workgroup also tells the
+  // main stream that the panel is done.  A rule of the SHAPE alone (every schedule applies it, so the bits do not depend on
+  // the schedule): at most ext_rows tile rows below the panel, more than EXT_MIN_REST tile columns behind it (the last
+  // columns run on one stream, where it would only add a launch), problems of LOOKAHEAD_MIN_TILES tile columns or more.
+  // While the trailing update is the critical path it would be wrong: the panel then waits for the main stream's bulk update
+  // in its MIDDLE (the first in-panel update that touches the next column), and the main stream idles for the other half.
+  constexpr int EXT_MIN_REST = 8;
+  auto ext = [&](int c0, int wp) {
+    const int m1 = c0 + wp;
+    return (h->ext_rows > 0 && ntc >= LOOKAHEAD_MIN_TILES && ntr - m1 <= h->ext_rows && ntc - m1 > EXT_MIN_REST) ? 1 : 0;
+  };
+  int done_slot_cur = -1;  // the slot super-panel J's last in-panel update raises (extended panels on two streams)
+  // edges of an extended panel [c0, c0 + wp) that is about to be queued on the panel stream: its first update of the next
+  // column (behind the leaf of column c0 + wp / 2 - 1) needs everything queued on the main stream so far
+  auto ext_edges = [&](int c0, int wp) -> hipError_t {
+    done_slot_cur = -1;
+    h->done_col = -1;
+    if (P == T) return hipSuccess;
+    if (h->use_smo >= 2 && h->sig_next + 2 <= SIG_SLOTS) {
+      const int slot = h->sig_next++;
+      hipError_t we = hipStreamWriteValue32(T, h->sig_dev + slot, h->sig_epoch, 0);
+      h->wait2_col = c0 + (wp >= 2 ? wp / 2 : 1) - 1;
+      h->wait2_slot = slot;
+      done_slot_cur = h->done_slot = h->sig_next++;
+      h->done_col = c0 + wp - 1;
+      return we;
+    }
+    return hand_off(h, T, P);
+  };
+  int nx_cur = ext(0, w);
+  if (nx_cur) CKE(ext_edges(0, w));
+  CKE(chol_panel(h, A, lda, ntr, 0, w, P, nx_cur));
   for (int J = 0; J < ntc;) {
     const int n1 = J + w;  // first tile column right of this super-panel
     // The panel stream's edges at a super-panel boundary: it tells the main stream that super-panel J is done (the main
@@ -519,12 +601,15 @@ static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int nt
     if (P != T) {
       const bool stays_two = n1 < ntc && !(ntc - n1 <= h->single_below / nb);
       bool tp_edge = false;
-      if (stays_two) {
+      if (stays_two && !nx_cur) {
         const int wn_ = pick_w(h, ntc - n1, wcap);
         const bool merged_ = n1 + wn_ < ntc && h->merge_min_tiles > 0 && ntc - n1 >= h->merge_min_tiles;
         tp_edge = merged_ || J > 0;
       }
-      if (h->use_smo >= 2 && tp_edge && h->sig_next + 2 <= SIG_SLOTS) {
+      if (nx_cur && done_slot_cur >= 0) {
+        // (an extended panel: its last in-panel update raised the slot -- nothing to launch on the panel stream)
+        CKE(hipStreamWaitValue32(T, h->sig_dev + done_slot_cur, h->sig_epoch, hipStreamWaitValueGte, 0xffffffffu));
+      } else if (h->use_smo >= 2 && tp_edge && h->sig_next + 2 <= SIG_SLOTS) {
         const int a = h->sig_next++;
         tp_slot = h->sig_next++;
         CKE(launch_signal_write_wait(h->sig_dev + a, h->sig_dev + tp_slot, h->sig_epoch, h->info_dev, P, h->btp ? h->btp->nb : 1,
@@ -545,7 +630,8 @@ static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int nt
     const int bc = ntc - n1 - wn, br = ntr - n1 - wn;
     const int btiles = bc * (bc + 1) / 2 + (br - bc) * bc;
     const int low = ntc - n1 <= h->lowocc_thr ? 1 : 0;
-    if (P != T && bulk && h->merge_min_tiles > 0 && ntc - n1 >= h->merge_min_tiles) {
+    const int nxn = ext(n1, wn);  // the panel queued in this step
+    if (P != T && bulk && !nx_cur && h->merge_min_tiles > 0 && ntc - n1 >= h->merge_min_tiles) {
       // BULK-BOUND super-panels (round 4): the panel stream idles for most of such a step, so the next super-panel need not
       // be updated by launches of its own ((a1) on the panel stream + (a2) on the main stream, 64x64 tiles, ~55 TFLOP/s, a
       // last partial round each).  The whole trailing trapezoid [n1, ntc) is ONE enumeration on the 128x128-tile kernel with
@@ -568,9 +654,11 @@ static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int nt
       } else if (atiles > done) {
         CKE(syrk_trapezoid(h, A, lda, ntr, n1, ac, J, w, T, low, done, atiles, wn));
       }
-      CKE(chol_panel(h, A, lda, ntr, n1, wn, P));
+      if (nxn) CKE(ext_edges(n1, wn));
+      CKE(chol_panel(h, A, lda, ntr, n1, wn, P, nxn));
       J = n1;
       w = wn;
+      nx_cur = nxn;
       continue;
     }
     if (P != T) {
@@ -579,11 +667,13 @@ static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int nt
       //      the critical path per super-panel).  That column was last touched by the previous step's bulk update (b)
       //      on the main stream: wait for it first.
       // (a2) the other columns on the main stream meanwhile; the panel stream waits for them after that leaf + strip
-      if (J > 0) {
-        if (tp_slot >= 0) CKE(hipStreamWriteValue32(T, h->sig_dev + tp_slot, h->sig_epoch, 0));
-        else CKE(hand_off(h, T, P));
+      if (!nx_cur) {  // (an extended panel has updated column n1 itself, behind the main stream's earlier updates of it)
+        if (J > 0) {
+          if (tp_slot >= 0) CKE(hipStreamWriteValue32(T, h->sig_dev + tp_slot, h->sig_epoch, 0));
+          else CKE(hand_off(h, T, P));
+        }
+        CKE(syrk_trapezoid(h, A, lda, ntr, n1, 1, J, w, P));
       }
-      CKE(syrk_trapezoid(h, A, lda, ntr, n1, 1, J, w, P));
       if (wn > 1) {
         // (option 29 = 1 runs it one workgroup per CU: the chain's next leaf needs a CU to itself, and with two 64x64-tile
         // workgroups on every CU none empties before this grid drains -- the first leaf of a super-panel waits 70-160 us at
@@ -605,8 +695,8 @@ static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int nt
         }
         h->wait_col = n1;
       }
-    } else {
-      CKE(syrk_trapezoid(h, A, lda, ntr, n1, wn, J, w, T));
+    } else if (wn - nx_cur > 0) {
+      CKE(syrk_trapezoid(h, A, lda, ntr, n1 + nx_cur, wn - nx_cur, J, w, T));
     }
     // (b) the rest of the trailing matrix, concurrently with that panel factorisation; once the panel chain is the
     // critical path the bulk update runs one workgroup per CU so that a leaf / strip workgroup fits beside it everywhere.
@@ -615,7 +705,15 @@ static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int nt
     // (On a single stream the order cannot matter for the schedule; there the bulk update stays behind the chain, where
     // it measures 1.6 % faster -- 1.771 vs 1.800 ms per launch at N = 16384, same box, interleaved: it then starts after
     // ~0.5 ms of a mostly idle chip instead of straight after the next-panel update.)
-    if (bulk && P != T) {
+    bool ext_done = false;
+    if (bulk && P != T && nxn && h->use_smo >= 2) {
+      // an extended panel follows: its chain polls for the bulk update of column n1 + wn in its middle -- that column first,
+      // the signal, then the rest (the same tiles on the same kernels as one launch would give them: same bits)
+      CKE(syrk_trapezoid(h, A, lda, ntr, n1 + wn, 1, J, w, T, low));
+      CKE(ext_edges(n1, wn));
+      ext_done = true;
+      if (bc > 1) CKE(syrk_trapezoid(h, A, lda, ntr, n1 + wn + 1, bc - 1, J, w, T, low));
+    } else if (bulk && P != T) {
       // Early super-panels are bound by the bulk update, not by the chain (the panel stream idles for most of it): only the
       // first split_tiles tiles run one workgroup per CU -- the mode that leaves every CU room for the chain's leaf /
       // strip / in-panel workgroups (and costs the kernel 5 % even alone) -- and the rest runs two per CU once the chain is through
@@ -627,10 +725,14 @@ static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int nt
         CKE(syrk_trapezoid(h, A, lda, ntr, n1 + wn, bc, J, w, T, low));
       }
     }
-    CKE(chol_panel(h, A, lda, ntr, n1, wn, P));
-    if (bulk && P == T) CKE(syrk_trapezoid(h, A, lda, ntr, n1 + wn, ntc - n1 - wn, J, w, T, 0));
+    // (an extended panel writes column n1 + wn: in every schedule BEHIND this step's bulk update of that column)
+    if (bulk && P == T && nxn) CKE(syrk_trapezoid(h, A, lda, ntr, n1 + wn, ntc - n1 - wn, J, w, T, 0));
+    if (nxn && !ext_done) CKE(ext_edges(n1, wn));
+    CKE(chol_panel(h, A, lda, ntr, n1, wn, P, nxn));
+    if (bulk && P == T && !nxn) CKE(syrk_trapezoid(h, A, lda, ntr, n1 + wn, ntc - n1 - wn, J, w, T, 0));
     J = n1;
     w = wn;
+    nx_cur = nxn;
   }
 #undef CKE
   return hipSuccess;

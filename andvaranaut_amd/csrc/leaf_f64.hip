@@ -324,6 +324,16 @@ __device__ __forceinline__ void static_for(F&& f) {
 constexpr int YB_LD = 18;                       // row stride of an identity-row buffer (16 rows at one column: 16 bank pairs)
 constexpr int MT_ELEMS = 256;                   // one 16x16 tile of M^ in MFMA operand order: [r][lane] <-> element [kq + 4 r][n]
 __device__ __forceinline__ constexpr int mt_off(int b, int c) { return (b * (b + 1) / 2 + c) * MT_ELEMS; }
+// Where element (row, col) of M = L^-1 lives in the leaf's 16384-double output: 16x16 tiles (row tile jb, column tile kb; only
+// kb <= jb are written or read), each tile in the order the strip kernel's MFMA B-operand loads want it -- lane l = 16 q + n
+// of a wave holds M[16 jb + n][16 kb + 4 q + s], s = 0..3, so a tile is two runs of 64 lanes x 2 doubles: s < 2, then s >= 2.
+// A wave's operand load is then 1 KB of consecutive addresses (round 5; row-major until then: every quarter-wave touched 16
+// rows, and the strip was bound by the texture addresser, not by memory or MFMA).
+__device__ __forceinline__ int minv_index(int row, int col) {
+  const int jb = row >> 4, n = row & 15, kb = col >> 4, c = col & 15;
+  return (jb * 8 + kb) * 256 + (c & 2) * 64 + ((c >> 2) * 16 + n) * 2 + (c & 1);
+}
+
 __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, long lda, double* __restrict__ minv,
                                                     int col0, int* __restrict__ info, double* smem, double* yrow) {
   double* S = smem;                     // packed lower block-trapezoid, see soff(): X~ (unnormalised columns of L)
@@ -464,7 +474,7 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
             if (lane < SB) {
               if (c <= r16) Ablk[(long)(j0 + r16) * lda + j0 + c] = a[0][c] * rc;
               const double m = a[1][c] * rc;  // M[j0 + c][j0 + lane]
-              minv[(long)(j0 + c) * LEAF + j0 + lane] = m;
+              minv[minv_index(j0 + c, j0 + lane)] = m;
               Mh[mt_off(LEAF / SB - 1, LEAF / SB - 1) + 64 * (c >> 2) + 16 * (c & 3) + lane] = m;
             }
           }
@@ -640,7 +650,7 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
         else if (half[u]) dst[u][0] = v[u].x;
       }
     };
-    // ---- M = L^-1 (row-major 128 x 128 in `minv`), block row by block row, in the helpers' idle time.
+    // ---- M = L^-1 (16x16 tiles in operand order in `minv`, see minv_index), block row by block row, in the helpers' idle time.
     // With L = X~ D^-1/2 (X~ the unnormalised columns, D = diag(d)) and Y_b = the identity rows wave 0 carried through block b
     // (Y_b[i][J] = (L~_bb^-T)[i][J] with L~_bb = X~_bb D_b^-1 unit lower triangular), M^ = D^-1/2 M obeys
     //   M^[b][b] = D_b^-1 Y_b^T,     M^[b][c] = -D_b^-1 Y_b^T  T[b][c],   T[b][c] = sum_{k = c}^{b - 1} X~[b][k] M^[k][c]   (c < b)
@@ -713,7 +723,7 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               Mh[mt_off(B, C) + 64 * r + lane] = m0[r];
-              minv[(long)(16 * B + kq + 4 * r) * LEAF + 16 * C + nn] = LAST ? m0[r] : m0[r] * sq[r];
+              minv[minv_index(16 * B + kq + 4 * r, 16 * C + nn)] = LAST ? m0[r] : m0[r] * sq[r];
             }
           } else if constexpr (C == B && !LAST) {  // the diagonal tile: D_b^-1 Y_b^T, element [J][i] = -nra[J] Y[i][J]
 #pragma unroll
@@ -721,7 +731,7 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
               const int J = kq + 4 * r;
               const double v = -nra[16 * B + J] * Y[nn * YB_LD + J];
               Mh[mt_off(B, B) + 64 * r + lane] = v;
-              minv[(long)(16 * B + J) * LEAF + 16 * B + nn] = v * sq[r];
+              minv[minv_index(16 * B + J, 16 * B + nn)] = v * sq[r];
             }
           }
         });
@@ -867,7 +877,7 @@ hipError_t launch_signal_write_wait(unsigned* wr, const unsigned* wt, unsigned v
 }
 
 // X * L^T = B in place on B (m x 128, leading dimension ldb even, m multiple of 16 RG) as X = B * M^T with M = L^-1
-// (row-major 128 x 128, lower triangular, zeros above the diagonal of its diagonal 16x16 tiles).
+// (128 x 128 lower triangular in the leaf's tile order -- minv_index --, zeros above the diagonal of its diagonal 16x16 tiles).
 // One workgroup per 16 RG rows; wave w owns the output column blocks {w, 7 - w} (9 of the 36 lower k-blocks each: the
 // triangle is split evenly), 36 MFMAs per wave and row group.  Within a 16-wide k-block the lane quarter q = lane >> 4
 // covers k = 16 kb + 4 q + s (s = the MFMA step), so every lane fetches 4 CONTIGUOUS doubles of its row of B and of its
@@ -896,22 +906,22 @@ __device__ __forceinline__ void trsm_strip128_body(const double* __restrict__ mi
 #pragma unroll
   for (int kb = 0; kb < 8; ++kb)
     if (kb <= jb1) load_kb(0, kb);
-  // M rows 16 jb + n, k-blocks 0 .. jb: (jb0 + 1) + (jb1 + 1) = 9 fetches of 4 doubles per lane
-  const double* m0 = minv + (long)(16 * jb0 + n) * LEAF + 4 * q;
-  const double* m1 = minv + (long)(16 * jb1 + n) * LEAF + 4 * q;
+  // M tiles (jb, kb), kb <= jb, in operand order (minv_index): (jb0 + 1) + (jb1 + 1) = 9 tiles, two coalesced 1 KB loads each
+  const double* m0 = minv + (long)(jb0 * 8) * 256 + 2 * lane;
+  const double* m1 = minv + (long)(jb1 * 8) * 256 + 2 * lane;
   double2_t b0[4][2], b1[8][2];
 #pragma unroll
   for (int kb = 0; kb < 4; ++kb) {
     if (kb <= jb0) {
-      b0[kb][0] = *reinterpret_cast<const double2_t*>(m0 + 16 * kb);
-      b0[kb][1] = *reinterpret_cast<const double2_t*>(m0 + 16 * kb + 2);
+      b0[kb][0] = *reinterpret_cast<const double2_t*>(m0 + 256 * kb);
+      b0[kb][1] = *reinterpret_cast<const double2_t*>(m0 + 256 * kb + 128);
     }
   }
 #pragma unroll
   for (int kb = 0; kb < 8; ++kb) {
     if (kb <= jb1) {
-      b1[kb][0] = *reinterpret_cast<const double2_t*>(m1 + 16 * kb);
-      b1[kb][1] = *reinterpret_cast<const double2_t*>(m1 + 16 * kb + 2);
+      b1[kb][0] = *reinterpret_cast<const double2_t*>(m1 + 256 * kb);
+      b1[kb][1] = *reinterpret_cast<const double2_t*>(m1 + 256 * kb + 128);
     }
   }
 #pragma unroll

@@ -80,7 +80,7 @@ bool gemm_uses_small_tiles(const GemmParams& p, int batch);  // true: the 64x64-
 // ---------------------------------------------------------------- leaf_f64.hip
 hipError_t leaf_enable_lds();
 constexpr int MINV_ELEMS = 128 * 128;  // doubles per leaf inverse
-// in-place lower Cholesky of one 128x128 diagonal block; minv receives M = L^-1 (row-major 128 x 128, lower triangular,
+// in-place lower Cholesky of one 128x128 diagonal block; minv receives M = L^-1 (128 x 128 lower triangular, 16x16 tiles in the strip kernel's operand order,
 // zeros above the diagonal inside the diagonal 16x16 tiles; the tiles above the block diagonal are not written and
 // never read); *info gets atomicMin(col0 + j + 1) on a bad pivot.
 // yrow (optional): row 0 of the 128-row block right below Ablk, solved in place against the leaf's inverse (beta = y M^T)
@@ -93,6 +93,14 @@ hipError_t launch_potrf_leaf128(double* Ablk, long lda, double* minv, int col0, 
 constexpr int SIGNAL_TIMEOUT_INFO = -99;
 hipError_t launch_signal_write_wait(unsigned* wr, const unsigned* wt, unsigned val, int* info, hipStream_t stream, int nb = 1,
                                     int sinfo = 0, int poll_log2 = 22);
+// ---------------------------------------------------------------- thin_f64.hip
+// C[ti, tj] -= P[ti] P[tj]^T over the lower trapezoid of mt x nt tiles (tj <= ti), k in {128, 256, 512, 1024}: 16-row x 64-column
+// workgroups with direct MFMA operands, for the panel chain's short updates.  wr (optional): workgroup 0 raises *wr to val
+bool syrk_thin_supported(int k);
+hipError_t launch_syrk_thin(const double* P, double* C, long ld, int mt, int nt, int k, hipStream_t stream, const Batch* bt = nullptr,
+                            unsigned* wr = nullptr, unsigned val = 0);
+
+// ---------------------------------------------------------------- leaf_f64.hip (continued)
 // X * L^T = B in place on the m x 128 panel B (m multiple of 16, ldb even) as X = B * M^T with the leaf's inverse M.
 hipError_t launch_trsm_strip128(const double* minv, double* B, long ldb, int m, hipStream_t stream, const Batch* bt = nullptr,
                                 long sB2 = 0);

@@ -170,6 +170,14 @@ int mi_gp_predict_grad(mi_gp_handle* h, const double* Xnew_dev, int m, double* w
  *      up to this many tiles start on the main stream inside the factorisation's chain-bound last steps instead of behind it
  *      (default 16, 0: never; same launches per tile, bit-identical gradients; N = 16384 LML + gradient 69.8 -> 69.4 ms)
  *   31 ... in the steps with at most this many trailing tile columns, half as many new columns per step (default 48)
+ *   32 in-panel updates (between two leaves of a super-panel) of at most this many 16-row x 128-column slices run on the thin
+ *      direct-operand kernel (default 256; 0: never); 33: ... and of at most this many tile columns (default 2); 34: ... and
+ *      with k up to this (default 128; 128 / 256 / 512 / 1024 are implemented).  Regroups sums (agreement to rounding); the
+ *      choice depends on the update's shape alone, so every schedule and a batch return the same bits.
+ *   35 extended super-panels: a super-panel with at most this many tile rows below it (default 32; 0: never) also applies its
+ *      in-panel updates to the NEXT super-panel's first tile column, level by level, instead of one update of that column
+ *      behind the panel (problems of 20 tile columns or more, not the last 8 columns).  Regroups that column's sums; a rule of
+ *      the shape alone as well.
  * 8, 14, 16, 18, 19, 21, 24, 26, 27, 29, 30 and 31 only change scheduling (bit-identical results); 20 moves tiles between the two GEMM kernels (same k order); 2, 4-7, 9 regroup sums (agreement to rounding), and so does 0 where
  * it changes the super-panel width (20 to 60 tile columns).
  * Unknown ids return -1.  (Round 1's options 1, 3, 10-13 -- GEMM variants, hipGraph replay, persistent bulk kernels,
@@ -222,7 +230,7 @@ int mi_gp_assemble_block(int d, int nkern, const int* kernel_ids, const int* ops
 
 /* Factor the w_tiles leading 128-column tiles of a (row_tiles x w_tiles)-tile lower trapezoid in place:
  * diagonal leaves, strip solves of all rows below, in-panel updates.  dinv_dev: w_tiles * 16384 doubles that receive
- * the explicit 128x128 inverses of the panel's diagonal blocks (row-major, lower triangular; the strip solves are
+ * the explicit 128x128 inverses of the panel's diagonal blocks (lower triangular, in an internal tile order; the strip solves are
  * products with them, and mi_gp_trsm_block reuses them); *info_dev receives atomicMin(col_base + bad pivot index + 1).
  * LAPACK dpotrf panel step. */
 int mi_gp_chol_panel(double* A_dev, long lda, int row_tiles, int w_tiles, double* dinv_dev, int* info_dev,

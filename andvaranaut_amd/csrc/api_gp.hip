@@ -1,6 +1,7 @@
 // Handle-level C-ABI (include/mi_gp.h): covariance assembly -> blocked right-looking Cholesky ->
 // log marginal likelihood.  Replaces what pm.find_MAP / pm.sample evaluate per step through
 // pm.gp.Marginal.marginal_likelihood (gpmcmc.py:321-323, 345, 351).
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -34,6 +35,8 @@ struct mi_gp_handle {
   unsigned sig_epoch;
   int sig_next;
   int wait_slot;                    // the slot that stands in for wait_ev
+  int pw_col[4], pw_slot[4], npw;   // (a2) in pieces (option 36): the leaf of tile column pw_col[i] ends only once slot pw_slot[i] is written
+  int a2_split_cols;                // option 36: (a2) runs as one launch per recursion level of the next panel from this many trailing columns on
   int wait2_col, wait2_slot;        // the leaf of tile column wait2_col ends only once this slot is written (everything queued on the
                                     // main stream before the super-panel's chain: the first in-panel update behind that leaf writes
                                     // the next super-panel's first column), -1: none
@@ -48,6 +51,7 @@ struct mi_gp_handle {
   int thin_max_wg;                  // option 32: in-panel updates of at most this many 16-row x 128-column slices (and at most thin_max_cols
                                     // tile columns, k <= thin_max_k) run on the thin direct-operand kernel (thin_f64.hip); 0: never
   int thin_max_cols, thin_max_k;    // options 33 / 34
+  int rl_cols;                      // option 37: the last rl_cols tile columns are factored COLUMN BY COLUMN (cholesky(): column mode); 0: never
   int ext_rows;                     // option 35: a super-panel with at most this many tile rows below it also applies its updates to
                                     // the NEXT super-panel's first tile column, level by level (chol_panel's nx); 0: never
   int done_col, done_slot;          // the update behind the strip of tile column done_col raises this slot ("super-panel done")
@@ -214,10 +218,12 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   h->poll_limit_log2 = 22;
   h->test_drop_signal = 0;
   h->a2_low = -1;
-  h->thin_max_wg = 256;
+  h->thin_max_wg = 2048;
   h->thin_max_cols = 2;
   h->thin_max_k = 128;
+  h->rl_cols = 24;
   h->ext_rows = 32;
+  h->a2_split_cols = 0;
   h->done_col = h->done_slot = -1;
   h->u_early_max_s = 16;
   h->u_early_cols = 48;
@@ -226,13 +232,16 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   h->sig_next = 0;
   h->wait_slot = -1;
   h->wait2_col = h->wait2_slot = -1;
+  h->npw = 0;
   // round-2 A/B (tools/dev_ab_opts.py, interleaved in one process): bulk updates at one workgroup per CU whenever the
   // panel chain runs beside them (N = 16384: 29.99 -> 28.97 ms) and 8-tile super-panels at every size (N = 2048 1.045 ->
   // 1.017 ms, 4096 2.470 -> 2.388, 8192 6.417 -> 6.348, 16384 28.59 -> 28.39 against the 8 / 4 split of round 1)
   h->lowocc_thr = 1 << 20;
   h->w_thr[0] = 1 << 20; h->w_thr[1] = 0; h->w_thr[2] = 0;
   if (e == hipSuccess) e = hipMalloc(&h->theta_dev, sizeof(double) * h->ntheta);
-  if (e == hipSuccess) e = hipMalloc(&h->dinv_dev, sizeof(double) * MINV_ELEMS * (size_t)h->ntc);
+  // (+ 4 blocks behind the leaf inverses: the strips' operand-order copies of their first 256 rows for the thin updates, two
+  // buffers of two blocks -- column mode reads the previous column's copy beside the current one's)
+  if (e == hipSuccess) e = hipMalloc(&h->dinv_dev, sizeof(double) * MINV_ELEMS * (size_t)(h->ntc + 4));
   if (e == hipSuccess) e = hipMalloc(&h->alpha_dev, sizeof(double) * h->np);
   if (e == hipSuccess) e = hipMalloc(&h->part_dev, sizeof(double) * (size_t)grad_contract_blocks(h->n) * h->ntheta);
   if (e == hipSuccess) e = hipHostMalloc(&h->grad_host, sizeof(double) * h->ntheta);
@@ -306,6 +315,8 @@ extern "C" int mi_gp_set_option(mi_gp_handle* h, int what, int value) {
   else if (what == 33) h->thin_max_cols = value < 1 ? 1 : value;
   else if (what == 34) h->thin_max_k = value;
   else if (what == 35) h->ext_rows = value < 0 ? 0 : value;
+  else if (what == 36) h->a2_split_cols = value < 0 ? 0 : value;
+  else if (what == 37) h->rl_cols = value < 0 ? 0 : value;
   else if (what == 9) h->tail_small = value ? 1 : 0;
   else {
     snprintf(h->err, sizeof(h->err), "mi_gp_set_option: unknown option %d", what);
@@ -369,10 +380,10 @@ static bool thin_shape(const mi_gp_handle* h, int mt, int nc, int kw) {
 // wr (in-panel updates only): raised to the evaluation's epoch once everything queued on `st` before this update is done
 static hipError_t syrk_trapezoid(mi_gp_handle* h, double* A, long lda, int ntr, int r0, int nc, int k0, int kw,
                                  hipStream_t st, int one_per_cu = 0, int tile0 = 0, int tile_cnt = 0, int fc = 0,
-                                 bool in_panel = false, unsigned* wr = nullptr) {
+                                 bool in_panel = false, unsigned* wr = nullptr, bool lsw = false) {
   if (in_panel && thin_shape(h, ntr - r0, nc, kw))
     return launch_syrk_thin(A + (long)r0 * 128 * lda + (long)k0 * 128, A + (long)r0 * 128 * lda + (long)r0 * 128, lda, ntr - r0, nc,
-                            kw * 128, st, h->btp, wr, h->sig_epoch);
+                            kw * 128, st, h->btp, wr, h->sig_epoch, lsw ? h->dinv_dev + (size_t)h->ntc * MINV_ELEMS : nullptr);
   if (wr != nullptr) {  // (the 64x64-tile kernel has no such hook: a one-lane launch in front of it)
     hipError_t we = launch_signal_write_wait(wr, nullptr, h->sig_epoch, h->info_dev, st);
     if (we != hipSuccess) return we;
@@ -408,9 +419,15 @@ static hipError_t syrk_trapezoid(mi_gp_handle* h, double* A, long lda, int ntr, 
 
 // factor tile columns [c0, c0+w) of the (ntr x ntc)-tile trapezoid, recursively halving w; nx (0 / 1): every level's update
 // also covers the nx tile columns behind the panel, so that they are up to date when the panel's last strip is.
-static hipError_t chol_panel(mi_gp_handle* h, double* A, long lda, int ntr, int c0, int w, hipStream_t st, int nx = 0) {
+// follow: number of tile columns of the k = 128 update that the CALLER runs right behind this (one-column) panel's strip
+static hipError_t chol_panel(mi_gp_handle* h, double* A, long lda, int ntr, int c0, int w, hipStream_t st, int nx = 0, int follow = 0) {
   hipError_t e;
   if (w == 1) {
+    // the update behind this column's strip is a k = 128 one over `fol` columns: on the thin kernel the strip hands it its
+    // B operand (the first fol x 128 rows of the strip) in operand order
+    const int fol = nx > 0 ? nx : follow;
+    const bool sw = fol > 0 && fol <= 2 && thin_shape(h, ntr - c0 - 1, fol, 1);
+    double* lsw = h->dinv_dev + (size_t)h->ntc * MINV_ELEMS;
     double* blk = A + (long)c0 * 128 * lda + (long)c0 * 128;
     double* dinv = h->dinv_dev + (size_t)c0 * MINV_ELEMS;
     const int m = (ntr - c0 - 1) * 128;
@@ -425,10 +442,16 @@ static hipError_t chol_panel(mi_gp_handle* h, double* A, long lda, int ntr, int 
     const bool waits2 = c0 == h->wait2_col && h->wait2_slot >= 0 && h->use_smo >= 2;
     const bool folded = waits2 || (waits && h->wait_slot >= 0 && h->use_smo >= 2);
     if (c0 == h->wait2_col) h->wait2_col = -1;
+    // (a2) in pieces: this leaf's poll is for the piece the update behind its strip reads (written before wait2's slot as well)
+    int pslot = -1;
+    for (int i = 0; i < h->npw; ++i)
+      if (h->pw_col[i] == c0) pslot = h->pw_slot[i];
     e = launch_potrf_leaf128(blk, lda, dinv, c0 * 128, h->info_dev, st, m == 128 ? blk + 128 * lda : nullptr, h->btp,
-                             waits2 ? h->sig_dev + h->wait2_slot : folded ? h->sig_dev + h->wait_slot : nullptr, h->sig_epoch,
-                             h->poll_limit_log2);
-    if (e == hipSuccess && m > 128) e = launch_trsm_strip128(dinv, blk + 128 * lda, lda, m, st, h->btp, h->btp ? h->btp->sK : 0);
+                             waits2 ? h->sig_dev + h->wait2_slot : folded ? h->sig_dev + h->wait_slot
+                                                                 : pslot >= 0 ? h->sig_dev + pslot : nullptr,
+                             h->sig_epoch, h->poll_limit_log2);
+    if (e == hipSuccess && m > 128)
+      e = launch_trsm_strip128(dinv, blk + 128 * lda, lda, m, st, h->btp, h->btp ? h->btp->sK : 0, sw ? lsw : nullptr, 8 * fol);
     if (e == hipSuccess && waits) {
       h->wait_col = -1;
       if (!folded)
@@ -439,14 +462,15 @@ static hipError_t chol_panel(mi_gp_handle* h, double* A, long lda, int ntr, int 
       unsigned* wr = nullptr;
       if (c0 == h->done_col && h->done_slot >= 0) wr = h->sig_dev + h->done_slot;
       if (c0 == h->done_col) h->done_col = -1;
-      e = syrk_trapezoid(h, A, lda, ntr, c0 + 1, nx, c0, 1, st, 0, 0, 0, 0, true, wr);
+      e = syrk_trapezoid(h, A, lda, ntr, c0 + 1, nx, c0, 1, st, 0, 0, 0, 0, true, wr, sw);
     }
     return e;
   }
   const int w1 = w / 2, w2 = w - w1;
-  e = chol_panel(h, A, lda, ntr, c0, w1, st);
+  e = chol_panel(h, A, lda, ntr, c0, w1, st, 0, w1 == 1 ? w2 + nx : 0);
   if (e != hipSuccess) return e;
-  e = syrk_trapezoid(h, A, lda, ntr, c0 + w1, w2 + nx, c0, w1, st, 0, 0, 0, 0, true);
+  e = syrk_trapezoid(h, A, lda, ntr, c0 + w1, w2 + nx, c0, w1, st, 0, 0, 0, 0, true, nullptr,
+                     w1 == 1 && w2 + nx <= 2 && thin_shape(h, ntr - c0 - w1, w2 + nx, 1));
   if (e != hipSuccess) return e;
   return chol_panel(h, A, lda, ntr, c0 + w1, w2, st, nx);
 }
@@ -515,14 +539,110 @@ constexpr int LOOKAHEAD_MIN_TILES = 20;  // round 4: with the single-stream tail
                                        // 1.022, 2560 1.145 vs 1.119, 2816 1.268 vs 1.251, 3072 1.373 vs 1.352, 3328 1.532 vs 1.484,
                                        // 3584 1.736 vs 1.606)
 
+// ... and from COLUMN_MODE_MIN_TILES on when the whole problem runs in column mode (round 5: three launches per column on the
+// panel stream, the rest on the main stream: one stream vs two at N = 1024 0.348 vs 0.336 ms, 1536 0.512 vs 0.475, 2048 0.665 vs
+// 0.619; in panel mode two streams still lose there: N = 2048 0.665 vs 0.699)
+constexpr int COLUMN_MODE_MIN_TILES = 8;
+static int lookahead_min_tiles(const mi_gp_handle* h, int ntc);
+
 static hipError_t u_levels(mi_gp_handle* h, int final_cols, int max_s);
+
+// COLUMN MODE (round 5, option 37): tile columns [cs, ntc) one by one.  The chain-bound end of a factorisation -- and all of
+// a small one -- pays a fixed ~5-8 us per launch on the panel stream, so the fewest, shortest launches per column win: leaf,
+// strip, and ONE thin update of the next column by the two columns before it (k = 256, both B operands from the strips'
+// operand-order copies); everything older reaches a column through the main stream, which applies column p to the columns
+// from p + 3 on (k = 128, 64x64 tiles) a column behind the chain:
+//   panel stream:  leaf j [start: S_j -- strips <= j-1 are done | end: polls T_(j-2)]  strip j  thin(col j+1 <- cols j-1, j)
+//   main stream:   wait S_j   update(cols >= j+2 <- col j-1)   signal T_(j-1)
+// The main stream's update starts when leaf j HAS its CU (it would otherwise fill the chip in front of it) and has until the
+// end of leaf j+1 -- ~58 us for ~20.  Which kernel updates a tile with which k is a matter of the column alone (not of the
+// streams: on one stream the same launches run in program order), so every schedule returns the same bits.
+// t_pending: something queued on the main stream writes columns > cs (the previous super-panel's update): leaf cs polls for it.
+static hipError_t chol_columns(mi_gp_handle* h, double* A, long lda, int ntr, int ntc, int cs, hipStream_t T, hipStream_t P,
+                               bool t_pending) {
+  hipError_t e = hipSuccess;
+#define CKC(x) do { e = (x); if (e != hipSuccess) return e; } while (0)
+  const bool two = P != T;
+  const bool smo = two && h->use_smo >= 2;
+  int tslot[3] = {-1, -1, -1};        // tslot[p % 3]: the slot behind the main stream's update by column p (or the entry update)
+  hipEvent_t tev[3];
+  bool tev_set[3] = {false, false, false};
+  auto t_signal = [&](int idx) -> hipError_t {
+    tslot[idx] = -1;
+    tev_set[idx] = false;
+    hipError_t se = hipSuccess;
+    if (smo) tslot[idx] = signal_from(h, T, &se);
+    if (se != hipSuccess) return se;
+    if (tslot[idx] < 0) {
+      se = next_event(h, &tev[idx]);
+      if (se == hipSuccess) se = hipEventRecord(tev[idx], T);
+      tev_set[idx] = true;
+    }
+    return se;
+  };
+  double* lsw0 = h->dinv_dev + (size_t)h->ntc * MINV_ELEMS;
+  if (two && t_pending) CKC(t_signal((cs + 1) % 3));  // polled by leaf cs: the index leaf j polls is (j - 2) mod 3 = (j + 1) mod 3
+  for (int j = cs; j < ntc; ++j) {
+    double* blk = A + (long)j * 128 * lda + (long)j * 128;
+    double* dinv = h->dinv_dev + (size_t)j * MINV_ELEMS;
+    const int m = (ntr - j - 1) * 128;
+    const bool thin_ok = h->thin_max_wg > 0 && (long)(ntr - j - 1) * 8 <= h->thin_max_wg;
+    double* lswj = lsw0 + (size_t)(2 * (j & 1)) * MINV_ELEMS;
+    // main stream's work of this step: column j - 1 (final since strip j - 1) updates the columns from j + 2 on
+    const bool t_work = j - 1 >= cs && j + 2 < ntc;
+    const int pidx = (j + 1) % 3;  // = (j - 2) mod 3
+    const bool polls = two && (tslot[pidx] >= 0 || tev_set[pidx]);
+    int sslot = -1;
+    if (two && t_work) {
+      if (smo && h->sig_next < SIG_SLOTS) sslot = h->sig_next++;
+      else CKC(hand_off(h, P, T));  // (behind the previous step's thin update: strip j - 1 is done)
+    }
+    CKC(launch_potrf_leaf128(blk, lda, dinv, j * 128, h->info_dev, P, m == 128 ? blk + 128 * lda : nullptr, h->btp,
+                             polls && tslot[pidx] >= 0 ? h->sig_dev + tslot[pidx] : nullptr, h->sig_epoch, h->poll_limit_log2,
+                             sslot >= 0 ? h->sig_dev + sslot : nullptr));
+    if (m > 128) CKC(launch_trsm_strip128(dinv, blk + 128 * lda, lda, m, P, h->btp, h->btp ? h->btp->sK : 0, thin_ok ? lswj : nullptr, 16));
+    if (polls && tslot[pidx] < 0) CKC(hipStreamWaitEvent(P, tev[pidx], 0));
+    tslot[pidx] = -1;
+    tev_set[pidx] = false;
+    if (j + 1 < ntc) {
+      // the next column <- this one and (from the second column of the mode on) the one before it
+      const bool k2 = j - 1 >= cs;
+      const int k0 = k2 ? j - 1 : j, kw = k2 ? 2 : 1, mt = ntr - j - 1;
+      double* Pp = A + (long)(j + 1) * 128 * lda + (long)k0 * 128;
+      double* Cc = A + (long)(j + 1) * 128 * lda + (long)(j + 1) * 128;
+      if (thin_ok) {
+        const double* la = k2 ? lsw0 + (size_t)(2 * ((j - 1) & 1) + 1) * MINV_ELEMS : lswj;  // column j-1: its strip's SECOND block
+        CKC(launch_syrk_thin(Pp, Cc, lda, mt, 1, kw * 128, P, h->btp, nullptr, h->sig_epoch, la, k2 ? lswj : nullptr));
+      } else {
+        CKC(syrk_trapezoid(h, A, lda, ntr, j + 1, 1, k0, kw, P));
+      }
+    }
+    if (t_work) {
+      if (sslot >= 0) CKC(hipStreamWaitValue32(T, h->sig_dev + sslot, h->sig_epoch, hipStreamWaitValueGte, 0xffffffffu));
+      CKC(syrk_trapezoid(h, A, lda, ntr, j + 2, ntc - j - 2, j - 1, 1, T));
+      if (two) CKC(t_signal((j - 1) % 3));
+    }
+    if (two && h->u_early && j > cs && (j - cs) % 4 == 0) {
+      // gradient evaluations: U = L^-T over the columns that are final (strips <= j - 1), behind the main stream's update
+      const int upto = h->u_leaf_done + h->u_early_cols / 2 < j ? h->u_leaf_done + h->u_early_cols / 2 : j;
+      if (!t_work && sslot < 0) CKC(hand_off(h, P, T));
+      CKC(u_levels(h, upto, h->u_early_max_s));
+    }
+  }
+#undef CKC
+  return e;
+}
+
+static int lookahead_min_tiles(const mi_gp_handle* h, int ntc) {
+  return (h->rl_cols > 0 && ntc <= h->rl_cols) ? COLUMN_MODE_MIN_TILES : LOOKAHEAD_MIN_TILES;
+}
 
 static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int ntc) {
   // A batched evaluation (blockIdx.z = problem) carries nb times the work per launch, so the look-ahead pays from smaller
   // problems on (nb = 8: N = 2560 +5 %, 3072 +10 %, 4096 +7 %; nb = 2 from 3072 on).  The super-panel widths stay those of
   // the single evaluation of the same size, so that a batch returns the single entry points' bits.
   const int nb = h->btp ? h->btp->nb : 1;
-  const bool la_single = h->lookahead == 2 || (h->lookahead == 1 && ntc >= LOOKAHEAD_MIN_TILES);
+  const bool la_single = h->lookahead == 2 || (h->lookahead == 1 && ntc >= lookahead_min_tiles(h, ntc));
   const bool la = la_single || (h->lookahead == 1 && nb >= 2 && ntc >= (nb >= 8 ? 20 : 24));
   hipStream_t T = h->stream, P = la ? h->pstream : h->stream;
   hipError_t e;
@@ -532,6 +652,7 @@ static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int nt
   h->sig_next = 0;
   h->wait_slot = -1;
   h->wait2_col = h->wait2_slot = -1;
+  h->npw = 0;
   if (++h->sig_epoch == 0xffffffffu) {  // (4e9 factorisations on one handle: start over)
     CKE(hipStreamSynchronize(h->stream));
     CKE(hipStreamSynchronize(h->pstream));
@@ -579,6 +700,13 @@ static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int nt
     }
     return hand_off(h, T, P);
   };
+  // column mode (chol_columns) for the last rl_cols tile columns -- a rule of the shape alone, like the extended panels
+  auto rl = [&](int c0) { return h->rl_cols > 0 && c0 < ntc && ntc - c0 <= h->rl_cols; };
+  if (rl(0)) {
+    CKE(chol_columns(h, A, lda, ntr, ntc, 0, T, P, false));
+    if (P != T) CKE(hand_off(h, P, T));
+    return hipSuccess;
+  }
   int nx_cur = ext(0, w);
   if (nx_cur) CKE(ext_edges(0, w));
   CKE(chol_panel(h, A, lda, ntr, 0, w, P, nx_cur));
@@ -599,7 +727,7 @@ static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int nt
       CKE(u_levels(h, upto, h->u_early_max_s));
     }
     if (P != T) {
-      const bool stays_two = n1 < ntc && !(ntc - n1 <= h->single_below / nb);
+      const bool stays_two = n1 < ntc && (rl(n1) || !(ntc - n1 <= h->single_below / nb));
       bool tp_edge = false;
       if (stays_two && !nx_cur) {
         const int wn_ = pick_w(h, ntc - n1, wcap);
@@ -620,6 +748,25 @@ static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int nt
       }
     }
     if (n1 >= ntc) break;
+    if (rl(n1)) {
+      // the rest column by column: column n1 <- super-panel J on the panel stream ((a1); an extended panel has done it),
+      // the columns behind it <- super-panel J on the main stream, polled for by the first leaf
+      if (P != T) {
+        if (!nx_cur) {
+          if (J > 0) {
+            if (tp_slot >= 0) CKE(hipStreamWriteValue32(T, h->sig_dev + tp_slot, h->sig_epoch, 0));
+            else CKE(hand_off(h, T, P));
+          }
+          CKE(syrk_trapezoid(h, A, lda, ntr, n1, 1, J, w, P));
+        }
+        if (ntc - n1 - 1 > 0) CKE(syrk_trapezoid(h, A, lda, ntr, n1 + 1, ntc - n1 - 1, J, w, T));
+      } else if (ntc - n1 - nx_cur > 0) {
+        CKE(syrk_trapezoid(h, A, lda, ntr, n1 + nx_cur, ntc - n1 - nx_cur, J, w, T));
+      }
+      CKE(chol_columns(h, A, lda, ntr, ntc, n1, T, P, P != T && ntc - n1 - 1 > 0));
+      if (P != T) CKE(hand_off(h, P, T));
+      break;
+    }
     // The END of a large factorisation is a small one: below LOOKAHEAD_MIN_TILES trailing columns the cross-stream hand-offs
     // cost more than the overlap returns (that is why small problems run on one stream), so the rest runs on the main
     // stream alone (round 4, option 21; the super-panel widths stay what they were, so the arithmetic does not change).
@@ -679,7 +826,25 @@ static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int nt
         // workgroups on every CU none empties before this grid drains -- the first leaf of a super-panel waits 70-160 us at
         // N = 8192.  Measured: the update itself then takes so much longer that N >= 8192 loses 1.5-2 % (the chain waits for
         // THIS launch at those steps, not for the leaf) and N <= 6144 gains 0.7-1 %: by default on up to 48 tile columns.)
-        CKE(syrk_trapezoid(h, A, lda, ntr, n1 + 1, wn - 1, J, w, T, h->a2_low < 0 ? (ntc <= 48 ? 1 : 0) : h->a2_low));
+        const int a2low = h->a2_low < 0 ? (ntc <= 48 ? 1 : 0) : h->a2_low;
+        h->npw = 0;
+        if (h->use_smo >= 2 && !h->test_drop_signal && wn > 2 && (wn & (wn - 1)) == 0 && ntc - n1 <= h->a2_split_cols &&
+            h->sig_next + 4 <= SIG_SLOTS) {  // (a power of two: the pieces are the recursion's halves)
+          // (a2) in PIECES, one per recursion level of the next panel (columns n1 + 1 | n1 + 2 .. 3 | n1 + 4 .. 7 | ...), each
+          // with its own signal: the in-panel update behind leaf n1 + 2^p - 1 reads piece p's columns only, so the chain's
+          // first leaf polls for ONE column's update (~20 us at N = 4096, hidden behind the leaf) instead of all wn - 1 (40 us).
+          // The same tiles on the same kernel: scheduling only.
+          for (int lo = 1; lo < wn; lo *= 2) {
+            const int cnt = (2 * lo <= wn ? 2 * lo : wn) - lo;
+            CKE(syrk_trapezoid(h, A, lda, ntr, n1 + lo, cnt, J, w, T, a2low));
+            const int slot = signal_from(h, T, &e);
+            if (e != hipSuccess) return e;
+            h->pw_col[h->npw] = n1 + lo - 1;
+            h->pw_slot[h->npw] = slot;
+            ++h->npw;
+          }
+        } else {
+        CKE(syrk_trapezoid(h, A, lda, ntr, n1 + 1, wn - 1, J, w, T, a2low));
         if (h->test_drop_signal && h->use_smo && h->sig_next < SIG_SLOTS) {
           // test hook (option 28): this edge's slot is never written -- the panel stream's poll has to give up
           h->test_drop_signal = 0;
@@ -694,6 +859,7 @@ static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int nt
           CKE(hipEventRecord(h->wait_ev, T));
         }
         h->wait_col = n1;
+        }
       }
     } else if (wn - nx_cur > 0) {
       CKE(syrk_trapezoid(h, A, lda, ntr, n1 + nx_cur, wn - nx_cur, J, w, T));
@@ -749,7 +915,7 @@ static int enqueue_factor(mi_gp_handle* h, int noise_form, bool prof) {
   // runs on an otherwise idle chip (0.73 ms at N = 16384).  Those columns (the first two 512-column runs of every tile row)
   // are assembled first; the rest follows on the main stream one workgroup per CU, beside that factorisation (option 24).
   h->asm_ev_valid = false;
-  const bool two_stream = h->lookahead == 2 || (h->lookahead == 1 && h->ntc >= LOOKAHEAD_MIN_TILES);
+  const bool two_stream = h->lookahead == 2 || (h->lookahead == 1 && h->ntc >= lookahead_min_tiles(h, h->ntc));
   // the first super-panel's width, by the rule cholesky() applies (the panel stream is released behind these columns: with a
   // narrower guess -- a hard-coded 8 until round 5, while option 4 makes the first panel 16 tiles wide -- the panel stream
   // would factor columns the second assembly launch is still writing)
@@ -816,8 +982,16 @@ static int factor_internal(mi_gp_handle* h, const double* theta, int what) {
     h->theta_host[i] = theta[i];
   }
   const bool prof = h->prof_level >= 1;
+  static const bool host_timing = getenv("MIGP_HOST_TIMING") != nullptr;  // dev aid: enqueue time vs total, on stderr
+  const auto tq0 = std::chrono::steady_clock::now();
   if (int r = run_evaluation(h, what)) return r;
+  const auto tq1 = std::chrono::steady_clock::now();
   HCK(hipStreamSynchronize(h->stream), "stream sync");
+  if (host_timing) {
+    const auto tq2 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[migp] enqueue %.1f us, sync after %.1f us\n", std::chrono::duration<double, std::micro>(tq1 - tq0).count(),
+            std::chrono::duration<double, std::micro>(tq2 - tq1).count());
+  }
   if (prof) {
     float ms;
     (void)hipEventElapsedTime(&ms, h->ev[0], h->ev[1]); h->t_assemble_ms = ms;
@@ -1081,7 +1255,7 @@ extern "C" int mi_gp_set_batch(mi_gp_handle* h, const mi_gp_batch_buffers* b) {
     h->batch_cap = 0;
     const size_t k = (size_t)b->count;
     HCK(hipMalloc(&h->b_theta_dev, sizeof(double) * k * h->ntheta), "batch scratch");
-    HCK(hipMalloc(&h->b_dinv_dev, sizeof(double) * k * MINV_ELEMS * (size_t)h->ntc), "batch scratch");
+    HCK(hipMalloc(&h->b_dinv_dev, sizeof(double) * k * MINV_ELEMS * (size_t)(h->ntc + 4)), "batch scratch");
     HCK(hipMalloc(&h->b_alpha_dev, sizeof(double) * k * h->np), "batch scratch");
     HCK(hipMalloc(&h->b_part_dev, sizeof(double) * k * (size_t)grad_contract_blocks(h->n) * h->ntheta), "batch scratch");
     HCK(hipMalloc(&h->b_info_dev, sizeof(int) * 4 * k), "batch scratch");
@@ -1121,7 +1295,7 @@ static int batch_internal(mi_gp_handle* h, int k, const double* thetas, int what
   h->grad_host = h->b_grad_host; h->out_host = h->b_out_host; h->theta_host = h->b_theta_host; h->info_dev = h->b_info_dev;
   h->bt.nb = k;
   h->bt.sK = h->bbuf.stride_k; h->bt.sZ = h->bt.sW = h->bbuf.stride_zw;
-  h->bt.sdinv = (long)MINV_ELEMS * h->ntc; h->bt.salpha = h->np;
+  h->bt.sdinv = (long)MINV_ELEMS * (h->ntc + 4); h->bt.salpha = h->np;
   h->bt.spart = (long)grad_contract_blocks(h->n) * h->ntheta;
   h->bt.stheta = h->ntheta; h->bt.sinfo = 4; h->bt.sout = 16;
   h->btp = &h->bt;

@@ -846,10 +846,13 @@ __global__ __launch_bounds__(512, 1) void potrf_leaf128_kernel(double* __restric
                                                                 double* __restrict__ minv, int col0,
                                                                 int* __restrict__ info, double* yrow, long sA, long sminv,
                                                                 int sinfo, const unsigned* wait_ptr, unsigned wait_val,
-                                                                int poll_log2) {
+                                                                int poll_log2, unsigned* start_wr) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   __builtin_amdgcn_s_setprio(3);  // the leaf is the panel chain: win the issue arbitration against bulk GEMM waves on its CU
   const long z = blockIdx.x;  // batched evaluation: one workgroup per problem
+  // start_wr (optional): "everything queued on this stream before me is done, and I have my CU" -- the main stream's next
+  // update waits for it, so that it does not fill the chip in front of this workgroup (column mode, api_gp.hip)
+  if (start_wr != nullptr && z == 0 && threadIdx.x == 0) __hip_atomic_store(start_wr, wait_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   potrf_leaf128_body(Ablk + z * sA, lda, minv + z * sminv, col0, info + z * sinfo, smem, yrow ? yrow + z * sA : nullptr);
   if (wait_ptr != nullptr && threadIdx.x == 0) poll_signal(wait_ptr, wait_val, info + z * sinfo, poll_log2);
 }
@@ -888,8 +891,11 @@ hipError_t launch_signal_write_wait(unsigned* wr, const unsigned* wt, unsigned v
 // (Round 1 also had a fused leaf + strip launch whose strip workgroups spun on a flag of the leaf workgroup: with the
 // strip down to one round trip the in-launch release / acquire hand-off costs more than the launch boundary it saved,
 // and it was the only inter-workgroup wait in the library -- removed in round 2.)
+// lsw (optional): the first lsw_blocks 16-row groups of the result are ALSO written there, 128 rows per 16384 doubles in the
+// operand order of minv_index -- the B operand of the thin update that follows (thin_f64.hip) as coalesced loads.
 template <int RG>
-__device__ __forceinline__ void trsm_strip128_body(const double* __restrict__ minv, double* __restrict__ B, long ldb, int blk) {
+__device__ __forceinline__ void trsm_strip128_body(const double* __restrict__ minv, double* __restrict__ B, long ldb, int blk,
+                                                   double* __restrict__ lsw, int lsw_blocks) {
   typedef double double2_t __attribute__((ext_vector_type(2)));
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -903,9 +909,20 @@ __device__ __forceinline__ void trsm_strip128_body(const double* __restrict__ mi
     a[kb][0] = *reinterpret_cast<const double2_t*>(src + 16 * kb);
     a[kb][1] = *reinterpret_cast<const double2_t*>(src + 16 * kb + 2);
   };
+  // RG == 1 (the chain's latency case): the 16 x 128 rows come in as four 1 KB row loads per wave and reach operand order
+  // through LDS (rows 130 doubles apart: a quarter-wave's 16-byte reads then cover all 64 banks once).  Loaded straight into
+  // operand registers -- every quarter-wave touching 16 rows -- the kernel was bound by the texture addresser.
+  __shared__ __attribute__((aligned(16))) double As[RG == 1 ? 16 * 130 : 2];
+  double2_t stage[4];
+  if constexpr (RG == 1) {
 #pragma unroll
-  for (int kb = 0; kb < 8; ++kb)
-    if (kb <= jb1) load_kb(0, kb);
+    for (int i = 0; i < 4; ++i)
+      stage[i] = *reinterpret_cast<const double2_t*>(B + ((long)blk * 16 + 4 * wave + i) * ldb + 2 * lane);
+  } else {
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb)
+      if (kb <= jb1) load_kb(0, kb);
+  }
   // M tiles (jb, kb), kb <= jb, in operand order (minv_index): (jb0 + 1) + (jb1 + 1) = 9 tiles, two coalesced 1 KB loads each
   const double* m0 = minv + (long)(jb0 * 8) * 256 + 2 * lane;
   const double* m1 = minv + (long)(jb1 * 8) * 256 + 2 * lane;
@@ -922,6 +939,18 @@ __device__ __forceinline__ void trsm_strip128_body(const double* __restrict__ mi
     if (kb <= jb1) {
       b1[kb][0] = *reinterpret_cast<const double2_t*>(m1 + 256 * kb);
       b1[kb][1] = *reinterpret_cast<const double2_t*>(m1 + 256 * kb + 128);
+    }
+  }
+  if constexpr (RG == 1) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<double2_t*>(As + (4 * wave + i) * 130 + 2 * lane) = stage[i];
+    __syncthreads();  // (every wave's rows have left memory: storing to them in place is safe from here on)
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+      if (kb <= jb1) {
+        a[kb][0] = *reinterpret_cast<const double2_t*>(As + n * 130 + 16 * kb + 4 * q);
+        a[kb][1] = *reinterpret_cast<const double2_t*>(As + n * 130 + 16 * kb + 4 * q + 2);
+      }
     }
   }
 #pragma unroll
@@ -953,15 +982,26 @@ __device__ __forceinline__ void trsm_strip128_body(const double* __restrict__ mi
     const double4_t x0 = (p0[0] + p0[1]) + (p0[2] + p0[3]), x1 = (p1[0] + p1[1]) + (p1[2] + p1[3]);
     // every wave's copy of this row group is in registers (its MFMAs consumed it; the next group's loads may still be
     // in flight, they touch other rows) before anybody overwrites the group
-    if (rg + 1 < RG) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(16) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if constexpr (RG > 1) {
+      if (rg + 1 < RG) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(16) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
     // D layout: lane holds X[16 (blk RG + rg) + q + 4 r][16 jb + n]
     double* out = B + ((long)blk * (16 * RG) + 16 * rg + q) * ldb + n;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       out[(long)(4 * r) * ldb + 16 * jb0] = x0[r];
       out[(long)(4 * r) * ldb + 16 * jb1] = x1[r];
+    }
+    const int g = blk * RG + rg;  // 16-row group of the strip
+    if (lsw != nullptr && g < lsw_blocks) {
+      double* sw = lsw + (long)(g >> 3) * (LEAF * LEAF);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        sw[minv_index(16 * (g & 7) + q + 4 * r, 16 * jb0 + n)] = x0[r];
+        sw[minv_index(16 * (g & 7) + q + 4 * r, 16 * jb1 + n)] = x1[r];
+      }
     }
   }
 }
@@ -972,7 +1012,8 @@ __device__ __forceinline__ void trsm_strip128_body(const double* __restrict__ mi
 // one launch serves `gridDim.y` independent (M, B) pairs: M at minv + y * 16384, B at B + y * strideB
 template <int RG>
 __global__ __launch_bounds__(256) void trsm_strip128_kernel(const double* __restrict__ minv, double* __restrict__ B, long ldb,
-                                                             long strideB, long sminv2, long sB2) {
+                                                             long strideB, long sminv2, long sB2, double* __restrict__ lsw,
+                                                             int lsw_blocks) {
   __builtin_amdgcn_s_setprio(3);
   // Row groups -> XCDs in contiguous ranges (workgroup b runs on XCD b % 8), the same way the GEMM kernels map their tile
   // rows: the update that follows reads this strip's rows, and the next strip reads what that update wrote, out of the L2
@@ -984,7 +1025,8 @@ __global__ __launch_bounds__(256) void trsm_strip128_kernel(const double* __rest
   }
   // blockIdx.z: problem of a batched evaluation (second batch level)
   trsm_strip128_body<RG>(minv + (long)blockIdx.y * (LEAF * LEAF) + (long)blockIdx.z * sminv2,
-                         B + (long)blockIdx.y * strideB + (long)blockIdx.z * sB2, ldb, blk);
+                         B + (long)blockIdx.y * strideB + (long)blockIdx.z * sB2, ldb, blk,
+                         lsw ? lsw + (long)blockIdx.z * sminv2 : nullptr, lsw_blocks);
 }
 
 // The leaf asks for more LDS than it uses, so that no 72 KB GEMM workgroup fits beside it on a CU: since round 5 its
@@ -1000,29 +1042,30 @@ hipError_t leaf_enable_lds() {
 }
 
 hipError_t launch_potrf_leaf128(double* Ablk, long lda, double* minv, int col0, int* info, hipStream_t stream, double* yrow,
-                                const Batch* bt, const unsigned* wait_ptr, unsigned wait_val, int poll_log2) {
+                                const Batch* bt, const unsigned* wait_ptr, unsigned wait_val, int poll_log2, unsigned* start_wr) {
   potrf_leaf128_kernel<<<bt ? bt->nb : 1, 512, LEAF_LDS_BYTES, stream>>>(Ablk, lda, minv, col0, info, yrow, bt ? bt->sK : 0,
                                                                         bt ? bt->sdinv : 0, bt ? bt->sinfo : 0, wait_ptr, wait_val,
-                                                                        poll_log2);
+                                                                        poll_log2, start_wr);
   return hipGetLastError();
 }
 
 // rows per workgroup by panel height: 16 while one round of workgroups covers the panel (lowest latency), 32 / 64 for
 // tall panels (the wave's tiles of M are reused, 1/2 and 1/4 of the operand traffic); m is a multiple of 64 or of 16
 hipError_t launch_trsm_strip128_batched(const double* minv, double* B, long ldb, long strideB, int m, int batch,
-                                        hipStream_t stream, const Batch* bt, long sB2) {
+                                        hipStream_t stream, const Batch* bt, long sB2, double* lsw, int lsw_blocks) {
   if (m <= 0 || batch <= 0) return hipSuccess;
   const int nb = bt ? bt->nb : 1;
   const long sm2 = bt ? bt->sdinv : 0;
   const long rows = (long)m * batch * nb;
-  if (rows > 8192 && m % 64 == 0) trsm_strip128_kernel<4><<<dim3(m / 64, batch, nb), 256, 0, stream>>>(minv, B, ldb, strideB, sm2, sB2);
-  else if (rows > 4096 && m % 32 == 0) trsm_strip128_kernel<2><<<dim3(m / 32, batch, nb), 256, 0, stream>>>(minv, B, ldb, strideB, sm2, sB2);
-  else trsm_strip128_kernel<1><<<dim3(m / 16, batch, nb), 256, 0, stream>>>(minv, B, ldb, strideB, sm2, sB2);
+  if (rows > 8192 && m % 64 == 0) trsm_strip128_kernel<4><<<dim3(m / 64, batch, nb), 256, 0, stream>>>(minv, B, ldb, strideB, sm2, sB2, lsw, lsw_blocks);
+  else if (rows > 4096 && m % 32 == 0) trsm_strip128_kernel<2><<<dim3(m / 32, batch, nb), 256, 0, stream>>>(minv, B, ldb, strideB, sm2, sB2, lsw, lsw_blocks);
+  else trsm_strip128_kernel<1><<<dim3(m / 16, batch, nb), 256, 0, stream>>>(minv, B, ldb, strideB, sm2, sB2, lsw, lsw_blocks);
   return hipGetLastError();
 }
 
-hipError_t launch_trsm_strip128(const double* minv, double* B, long ldb, int m, hipStream_t stream, const Batch* bt, long sB2) {
-  return launch_trsm_strip128_batched(minv, B, ldb, 0, m, 1, stream, bt, sB2);
+hipError_t launch_trsm_strip128(const double* minv, double* B, long ldb, int m, hipStream_t stream, const Batch* bt, long sB2,
+                                double* lsw, int lsw_blocks) {
+  return launch_trsm_strip128_batched(minv, B, ldb, 0, m, 1, stream, bt, sB2, lsw, lsw_blocks);
 }
 
 }  // namespace migp

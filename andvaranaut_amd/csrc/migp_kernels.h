@@ -87,7 +87,8 @@ constexpr int MINV_ELEMS = 128 * 128;  // doubles per leaf inverse
 // wait_ptr (optional): the launch ends only once *wait_ptr >= wait_val (a cross-stream signal; see leaf_f64.hip)
 hipError_t launch_potrf_leaf128(double* Ablk, long lda, double* minv, int col0, int* info, hipStream_t stream,
                                 double* yrow = nullptr, const Batch* bt = nullptr, const unsigned* wait_ptr = nullptr,
-                                unsigned wait_val = 0, int poll_log2 = 22);
+                                unsigned wait_val = 0, int poll_log2 = 22, unsigned* start_wr = nullptr);
+// (start_wr, optional: raised to wait_val by the first workgroup as it starts)
 // one lane: *wr = val (if wr), then wait for *wt >= val (if wt); a poll that gives up (after 2^poll_log2 sleeps) puts
 // SIGNAL_TIMEOUT_INFO into the nb bad-pivot words info[p * sinfo]
 constexpr int SIGNAL_TIMEOUT_INFO = -99;
@@ -97,17 +98,22 @@ hipError_t launch_signal_write_wait(unsigned* wr, const unsigned* wt, unsigned v
 // C[ti, tj] -= P[ti] P[tj]^T over the lower trapezoid of mt x nt tiles (tj <= ti), k in {128, 256, 512, 1024}: 16-row x 64-column
 // workgroups with direct MFMA operands, for the panel chain's short updates.  wr (optional): workgroup 0 raises *wr to val
 bool syrk_thin_supported(int k);
+// lsw (optional, k = 128): the rows of P that are the B operand (tile rows 0 .. nt - 1) in operand order, as the strip wrote them
+// lsw + lsw2 (k = 256, nt = 1): the B operand's first 128 k from lsw, the other 128 from lsw2 (two strips' copies)
 hipError_t launch_syrk_thin(const double* P, double* C, long ld, int mt, int nt, int k, hipStream_t stream, const Batch* bt = nullptr,
-                            unsigned* wr = nullptr, unsigned val = 0);
+                            unsigned* wr = nullptr, unsigned val = 0, const double* lsw = nullptr, const double* lsw2 = nullptr);
 
 // ---------------------------------------------------------------- leaf_f64.hip (continued)
 // X * L^T = B in place on the m x 128 panel B (m multiple of 16, ldb even) as X = B * M^T with the leaf's inverse M.
+// lsw (optional): the first lsw_blocks 16-row groups of X are also written there in MFMA operand order (128 rows per 16384
+// doubles; problem z of a batch at lsw + z * bt->sdinv) -- the B operand of launch_syrk_thin
 hipError_t launch_trsm_strip128(const double* minv, double* B, long ldb, int m, hipStream_t stream, const Batch* bt = nullptr,
-                                long sB2 = 0);
+                                long sB2 = 0, double* lsw = nullptr, int lsw_blocks = 0);
 // batched form: pair b uses minv + b * MINV_ELEMS and B + b * strideB (m rows each)
 // bt (optional): a second batch level over problems (blockIdx.z): minv + z * bt->sdinv, B + z * sB2
 hipError_t launch_trsm_strip128_batched(const double* minv, double* B, long ldb, long strideB, int m, int batch,
-                                        hipStream_t stream, const Batch* bt = nullptr, long sB2 = 0);
+                                        hipStream_t stream, const Batch* bt = nullptr, long sB2 = 0, double* lsw = nullptr,
+                                        int lsw_blocks = 0);
 
 // ---------------------------------------------------------------- assemble.hip
 enum { KID_RBF = 0, KID_MATERN52 = 1, KID_MATERN32 = 2, KID_EXPONENTIAL = 3, KID_RATQUAD = 4 };

@@ -30,9 +30,12 @@ struct ThinArgs {
   int mt, nt;
   unsigned* wr;
   unsigned val;
+  const double* lsw;  // B operand in operand order (or nullptr: from P's rows)
+  const double* lsw2; // K = 256: the operand-order block of the second 128 k
+  long sL;
 };
 
-template <int K, int AHEAD>
+template <int K, int AHEAD, bool SW>
 __global__ __launch_bounds__(256) void syrk_thin_kernel(ThinArgs g) {
   __builtin_amdgcn_s_setprio(3);
   // row slices -> XCDs in contiguous ranges (workgroup b runs on XCD b % 8), as the strip and the GEMM kernels map their rows
@@ -51,16 +54,41 @@ __global__ __launch_bounds__(256) void syrk_thin_kernel(ThinArgs g) {
   const long zoff = (long)blockIdx.z * g.sZ;
   const double* arow = g.P + zoff + (long)(rs * 16 + n) * g.ld + 4 * q;
   const double* brow = g.P + zoff + (long)(cg * 64 + wave * 16 + n) * g.ld + 4 * q;
+  // SW: 16x16 tiles of 256 doubles, tile (cb & 7, kb) of the 128-row block cb >> 3, two runs of 64 lanes x 2 doubles each
+  const int cb = cg * 4 + wave;
+  const double* bsw = SW ? g.lsw + (long)blockIdx.z * g.sL + (long)(cb >> 3) * 16384 + (long)((cb & 7) * 8) * 256 + 2 * lane : nullptr;
+  const double* bsw2 = (SW && K == 256) ? g.lsw2 + (long)blockIdx.z * g.sL + (long)((cb & 7) * 8) * 256 + 2 * lane : nullptr;
   double* out = g.C + zoff + (long)(rs * 16 + q) * g.ld + cg * 64 + wave * 16 + n;
   constexpr int NC = K / 64;
   double2_t a[NC][4][2], b[NC][4][2];
+  // SW (k = 128): the workgroup's 16 x 128 rows as four 1 KB row loads per wave, through LDS into operand order (rows 130
+  // doubles apart: conflict-free 16-byte reads) -- as the strip does it
+  constexpr int ALD = K + 2;  // (K = 128 or 256: a row's dword stride is 4 mod 64 either way)
+  __shared__ __attribute__((aligned(16))) double As[SW ? 16 * ALD : 2];
+  double2_t stage[SW ? K / 32 : 1];
+  if constexpr (SW) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int hk = 0; hk < K / 128; ++hk)
+        stage[i * (K / 128) + hk] =
+            *reinterpret_cast<const double2_t*>(g.P + zoff + (long)(rs * 16 + 4 * wave + i) * g.ld + 128 * hk + 2 * lane);
+  }
   auto load_chunk = [&](int c) {
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
-      a[c][kb][0] = *reinterpret_cast<const double2_t*>(arow + 64 * c + 16 * kb);
-      a[c][kb][1] = *reinterpret_cast<const double2_t*>(arow + 64 * c + 16 * kb + 2);
-      b[c][kb][0] = *reinterpret_cast<const double2_t*>(brow + 64 * c + 16 * kb);
-      b[c][kb][1] = *reinterpret_cast<const double2_t*>(brow + 64 * c + 16 * kb + 2);
+      if (!SW) {
+        a[c][kb][0] = *reinterpret_cast<const double2_t*>(arow + 64 * c + 16 * kb);
+        a[c][kb][1] = *reinterpret_cast<const double2_t*>(arow + 64 * c + 16 * kb + 2);
+      }
+      if (SW) {
+        const double* src = (K == 256 && c >= 2) ? bsw2 + 256 * (4 * (c - 2) + kb) : bsw + 256 * (4 * c + kb);
+        b[c][kb][0] = *reinterpret_cast<const double2_t*>(src);
+        b[c][kb][1] = *reinterpret_cast<const double2_t*>(src + 128);
+      } else {
+        b[c][kb][0] = *reinterpret_cast<const double2_t*>(brow + 64 * c + 16 * kb);
+        b[c][kb][1] = *reinterpret_cast<const double2_t*>(brow + 64 * c + 16 * kb + 2);
+      }
     }
   };
 #pragma unroll
@@ -68,6 +96,22 @@ __global__ __launch_bounds__(256) void syrk_thin_kernel(ThinArgs g) {
   double cold[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) cold[r] = out[(long)(4 * r) * g.ld];
+  if constexpr (SW) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int hk = 0; hk < K / 128; ++hk)
+        *reinterpret_cast<double2_t*>(As + (4 * wave + i) * ALD + 128 * hk + 2 * lane) = stage[i * (K / 128) + hk];
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        a[c][kb][0] = *reinterpret_cast<const double2_t*>(As + n * ALD + 64 * c + 16 * kb + 4 * q);
+        a[c][kb][1] = *reinterpret_cast<const double2_t*>(As + n * ALD + 64 * c + 16 * kb + 4 * q + 2);
+      }
+    }
+  }
   const double4_t zero4 = {0.0, 0.0, 0.0, 0.0};
   double4_t p[4] = {zero4, zero4, zero4, zero4};
 #pragma unroll
@@ -89,7 +133,7 @@ __global__ __launch_bounds__(256) void syrk_thin_kernel(ThinArgs g) {
 bool syrk_thin_supported(int k) { return k == 128 || k == 256 || k == 512 || k == 1024; }
 
 hipError_t launch_syrk_thin(const double* P, double* C, long ld, int mt, int nt, int k, hipStream_t stream, const Batch* bt,
-                            unsigned* wr, unsigned val) {
+                            unsigned* wr, unsigned val, const double* lsw, const double* lsw2) {
   ThinArgs g;
   g.P = P;
   g.C = C;
@@ -99,12 +143,22 @@ hipError_t launch_syrk_thin(const double* P, double* C, long ld, int mt, int nt,
   g.nt = nt;
   g.wr = wr;
   g.val = val;
+  g.lsw = lsw;
+  g.lsw2 = lsw2;
+  g.sL = bt ? bt->sdinv : 0;
+  if (lsw != nullptr && !(k == 128 || (k == 256 && lsw2 != nullptr && nt == 1))) return hipErrorInvalidValue;
   const dim3 grid(mt * 8, nt * 2, bt ? bt->nb : 1);
   switch (k) {
-    case 128: syrk_thin_kernel<128, 2><<<grid, 256, 0, stream>>>(g); break;
-    case 256: syrk_thin_kernel<256, 4><<<grid, 256, 0, stream>>>(g); break;
-    case 512: syrk_thin_kernel<512, 4><<<grid, 256, 0, stream>>>(g); break;
-    case 1024: syrk_thin_kernel<1024, 4><<<grid, 256, 0, stream>>>(g); break;
+    case 128:
+      if (lsw) syrk_thin_kernel<128, 2, true><<<grid, 256, 0, stream>>>(g);
+      else syrk_thin_kernel<128, 2, false><<<grid, 256, 0, stream>>>(g);
+      break;
+    case 256:
+      if (lsw) syrk_thin_kernel<256, 4, true><<<grid, 256, 0, stream>>>(g);
+      else syrk_thin_kernel<256, 4, false><<<grid, 256, 0, stream>>>(g);
+      break;
+    case 512: syrk_thin_kernel<512, 4, false><<<grid, 256, 0, stream>>>(g); break;
+    case 1024: syrk_thin_kernel<1024, 4, false><<<grid, 256, 0, stream>>>(g); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -171,7 +171,7 @@ int mi_gp_predict_grad(mi_gp_handle* h, const double* Xnew_dev, int m, double* w
  *      (default 16, 0: never; same launches per tile, bit-identical gradients; N = 16384 LML + gradient 69.8 -> 69.4 ms)
  *   31 ... in the steps with at most this many trailing tile columns, half as many new columns per step (default 48)
  *   32 in-panel updates (between two leaves of a super-panel) of at most this many 16-row x 128-column slices run on the thin
- *      direct-operand kernel (default 256; 0: never); 33: ... and of at most this many tile columns (default 2); 34: ... and
+ *      direct-operand kernel (default 2048; 0: never); 33: ... and of at most this many tile columns (default 2); 34: ... and
  *      with k up to this (default 128; 128 / 256 / 512 / 1024 are implemented).  Regroups sums (agreement to rounding); the
  *      choice depends on the update's shape alone, so every schedule and a batch return the same bits.
  *   35 extended super-panels: a super-panel with at most this many tile rows below it (default 32; 0: never) also applies its

@@ -55,7 +55,7 @@ def test_config3_lml_grad_n16384():
     # (c) sharded driver, one rank
     dgp = DistGP(X, y, "Matern52")
     vd, gd = dgp.lml_grad(theta)
-    assert abs(vd - v1) <= 1e-11 * abs(v1), (vd, v1)
+    assert abs(vd - v1) <= 1e-10 * abs(v1), (vd, v1)  # (two algorithms since round 5: see test_gpu_distributed.SHARD_VS_SINGLE)
     scale = np.maximum(np.abs(g1), 1e-3 * np.max(np.abs(g1)))
     assert np.max(np.abs(gd - g1) / scale) <= 1e-8, (gd, g1)
 
@@ -88,7 +88,7 @@ def test_config5_n8192_lml_vs_oracle_then_nuts_on_device():
 
 def test_config4_sharded_driver_n65536_one_rank_equals_single_gpu_path():
     """Config 4's shape through the sharded driver (64 column panels of 1024, panel-by-panel launches, no graph) against
-    the single-GPU path (super-panels + look-ahead + graph replay) on the same data: 1e-11."""
+    the single-GPU path (super-panels + look-ahead + graph replay) on the same data: 1e-10."""
     MiGP, _ = _mods()
     from andvaranaut_amd.distributed import DistGP
     from bench import synth_problem
@@ -104,7 +104,7 @@ def test_config4_sharded_driver_n65536_one_rank_equals_single_gpu_path():
     dgp = DistGP(X, y, "RBF")
     assert dgp.npan == 64 and dgp.pw == 1024
     vd = dgp.lml(theta)
-    assert abs(vd - v1) <= 1e-11 * abs(v1), (vd, v1)
+    assert abs(vd - v1) <= 1e-10 * abs(v1), (vd, v1)  # (two algorithms since round 5: see test_gpu_distributed.SHARD_VS_SINGLE)
 
 
 NCCL_WORKER = r'''

@@ -9,6 +9,14 @@ import sys
 import numpy as np
 import pytest
 
+# The sharded driver and the single-GPU path are two ALGORITHMS since round 5 (block-cyclic panels with recursive in-panel
+# updates here; super-panels, extended panels and a column-by-column tail there): they round differently.  Until then the two
+# shared every launch of the chain and agreed to 1e-11.  Measured at cond(K) ~ 1e7 (tools, N = 900 RatQuad d = 2): the
+# single-GPU path is 4.9e-12 from the oracle, its round-4 arithmetic (option 37 = 0) 7.9e-12 on the other side, the sharded
+# path 1.1e-11 -- so two correct results may differ by 2e-11.  The bound is the contract's 1e-10, which each path also has to
+# keep against the oracle.
+SHARD_VS_SINGLE = 1e-10
+
 from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
@@ -48,7 +56,7 @@ def test_single_rank_wide_panels_match_single_gpu_path():
     val, g = gp.lml_grad(theta)
     one = MiGP(X, y, "Matern52")
     v1, g1 = one.lml_grad(theta)
-    assert abs(val - v1) <= 1e-11 * abs(v1)
+    assert abs(val - v1) <= SHARD_VS_SINGLE * abs(v1)
     assert _grad_close(g, g1, rtol=1e-8), (g, g1)
     assert abs(gp.lml(theta) - orc.lml(X, y, ["Matern52"], [], theta)) <= 1e-10 * abs(v1)
     one.close()
@@ -79,7 +87,7 @@ def test_single_rank_gradient_matches_oracle_and_single_gpu_path(N, d, kernel):
     assert _grad_close(g, gref), (g, gref)
     one = MiGP(X, y, kernel)
     v1, g1 = one.lml_grad(theta)
-    assert abs(val - v1) <= 1e-11 * abs(v1)
+    assert abs(val - v1) <= SHARD_VS_SINGLE * abs(v1)
     assert _grad_close(g, g1, rtol=1e-8), (g, g1)
     one.close()
     bad = theta.copy()
@@ -251,7 +259,7 @@ def test_kept_factor_of_the_sharded_gradient_equals_the_single_gpu_factor(chain_
         torch.cuda.synchronize()
         L = torch.tril(gp.Lf[:N, :N]).cpu().numpy()
         assert np.abs(L - L1).max() <= 1e-11 * np.abs(L1).max()
-        assert abs(val - v1) <= 1e-11 * abs(v1)
+        assert abs(val - v1) <= SHARD_VS_SINGLE * abs(v1)
         assert _grad_close(g, g1, rtol=1e-8), (g, g1)
     one.close()
 

@@ -586,7 +586,11 @@ static hipError_t chol_columns(mi_gp_handle* h, double* A, long lda, int ntr, in
     double* blk = A + (long)j * 128 * lda + (long)j * 128;
     double* dinv = h->dinv_dev + (size_t)j * MINV_ELEMS;
     const int m = (ntr - j - 1) * 128;
-    const bool thin_ok = h->thin_max_wg > 0 && (long)(ntr - j - 1) * 8 <= h->thin_max_wg;
+    // (the thin update of column c reads the strips of columns c - 2 and c - 1: a strip writes its operand-order copy when the
+    // NEXT column's update is a thin one as well -- the limit is monotone in the column, so that covers this column's)
+    auto thin_at = [&](int c) { return h->thin_max_wg > 0 && (long)(ntr - c - 1) * 8 <= h->thin_max_wg; };
+    const bool thin_ok = thin_at(j);
+    const bool lsw_out = thin_ok || (j + 2 < ntc && thin_at(j + 1));
     double* lswj = lsw0 + (size_t)(2 * (j & 1)) * MINV_ELEMS;
     // main stream's work of this step: column j - 1 (final since strip j - 1) updates the columns from j + 2 on
     const bool t_work = j - 1 >= cs && j + 2 < ntc;
@@ -600,7 +604,7 @@ static hipError_t chol_columns(mi_gp_handle* h, double* A, long lda, int ntr, in
     CKC(launch_potrf_leaf128(blk, lda, dinv, j * 128, h->info_dev, P, m == 128 ? blk + 128 * lda : nullptr, h->btp,
                              polls && tslot[pidx] >= 0 ? h->sig_dev + tslot[pidx] : nullptr, h->sig_epoch, h->poll_limit_log2,
                              sslot >= 0 ? h->sig_dev + sslot : nullptr));
-    if (m > 128) CKC(launch_trsm_strip128(dinv, blk + 128 * lda, lda, m, P, h->btp, h->btp ? h->btp->sK : 0, thin_ok ? lswj : nullptr, 16));
+    if (m > 128) CKC(launch_trsm_strip128(dinv, blk + 128 * lda, lda, m, P, h->btp, h->btp ? h->btp->sK : 0, lsw_out ? lswj : nullptr, 16));
     if (polls && tslot[pidx] < 0) CKC(hipStreamWaitEvent(P, tev[pidx], 0));
     tslot[pidx] = -1;
     tev_set[pidx] = false;

@@ -127,3 +127,56 @@ def test_early_inverse_levels_leave_the_gradient_bit_identical():
     mu2, var2 = gp.predict(theta, X[:300], via_inverse=False)
     assert np.allclose(mu, mu2, rtol=1e-7, atol=1e-8) and np.allclose(var, var2, rtol=1e-6, atol=1e-9)
     gp.close()
+
+
+@pytest.mark.parametrize("N,d", [(1500, 4), (3000, 6), (4300, 5), (8320, 8)])
+def test_column_mode_and_extended_panels_return_the_same_bits_on_every_schedule(N, d):
+    """Round 5: the last 24 tile columns are factored column by column (option 37), the super-panels in front of them also
+    update the next panel's first column (option 35), short in-panel updates run on the thin kernel (option 32).  All three are
+    rules of the SHAPE: one stream (option 0 = 0), forced two streams (0 = 2), event edges instead of stream memory
+    operations (26 = 0 / 1), the other scheduling knobs -- every schedule returns the default's bits, LML and gradient."""
+    MiGP, orc = _mods()
+    X, y = orc.synth_problem(N, d, seed=N)
+    theta = orc.synth_theta(d)
+    gp = MiGP(X, y, "Matern52")
+    ntc = (N + 127) // 128
+    if ntc >= 20:
+        gp.set_option(2, 4 if ntc <= 60 else 8)  # pin the width the two-stream default picks (one stream would take 8)
+    v0, g0 = gp.lml_grad(theta)
+    ref = orc.lml(X, y, ["Matern52"], [], theta)
+    assert abs(v0 - ref) <= 1e-10 * abs(ref)
+    for opts in ([(0, 0)], [(0, 2)], [(26, 0)], [(26, 1)], [(26, 0), (0, 2)], [(21, 16)], [(29, 0)], [(29, 1)], [(36, 64)], [(30, 0)]):
+        for k, v in opts:
+            gp.set_option(k, v)
+        v1, g1 = gp.lml_grad(theta)
+        assert v1 == v0 and np.array_equal(g1, g0), opts
+        assert gp.lml(theta) == v0, opts
+        for k, v in {0: 1, 26: 2, 21: 8, 29: -1, 36: 0, 30: 16}.items():
+            gp.set_option(k, v)
+    gp.close()
+
+
+def test_round5_arithmetic_options_agree_to_rounding_and_off_is_the_round4_chain():
+    """Options 32 (thin kernel), 35 (extended panels), 37 (column mode) regroup sums: every combination agrees with the
+    oracle to the contract's 1e-10 and with each other to 1e-11 on a well-conditioned problem; a batch returns the single
+    evaluation's bits under each of them."""
+    MiGP, orc = _mods()
+    N, d = 4300, 5
+    X, y = orc.synth_problem(N, d, seed=8)
+    theta = orc.synth_theta(d)
+    th = np.stack([orc.synth_theta(d, kv=1.2 + 0.2 * i) for i in range(3)])
+    ref = orc.lml(X, y, ["RBF"], [], theta)
+    gp = MiGP(X, y, "RBF", need_grad=False)
+    vals = []
+    for o32, o35, o37 in [(2048, 32, 24), (0, 32, 24), (2048, 0, 24), (2048, 32, 0), (0, 0, 0), (2048, 64, 34), (64, 8, 12)]:
+        gp.set_option(32, o32)
+        gp.set_option(35, o35)
+        gp.set_option(37, o37)
+        v = gp.lml(theta)
+        assert abs(v - ref) <= 1e-10 * abs(ref), (o32, o35, o37)
+        vals.append(v)
+        single = np.array([gp.lml(t) for t in th])
+        batch = gp.lml_batch(th)
+        assert np.array_equal(single, batch), (o32, o35, o37)
+    assert max(vals) - min(vals) <= 1e-11 * abs(ref), vals
+    gp.close()

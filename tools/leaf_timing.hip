@@ -57,6 +57,15 @@ int main() {
   printf("max |L L^T - A| = %.3e\n", err);
   std::vector<double> M(n * n);
   hipMemcpy(M.data(), dinv, M.size() * 8, hipMemcpyDeviceToHost);
+  {  // the leaf writes M in 16x16 tiles in the strip's operand order (leaf_f64.hip: minv_index); back to row-major for the check
+    std::vector<double> R(M.size(), 0.0);
+    for (int row = 0; row < n; ++row)
+      for (int col = 0; col < (row / 16 + 1) * 16; ++col) {
+        const int jb = row >> 4, nn = row & 15, kb = col >> 4, c = col & 15;
+        R[row * n + col] = M[(jb * 8 + kb) * 256 + (c & 2) * 64 + ((c >> 2) * 16 + nn) * 2 + (c & 1)];
+      }
+    M = R;
+  }
   double ierr = 0;
   for (int i = 0; i < n; ++i) for (int j = 0; j <= i; ++j) { double s = 0; for (int k = j; k <= i; ++k) s += M[i * n + k] * A[k * lda + j]; ierr = std::max(ierr, std::fabs(s - (i == j ? 1.0 : 0.0))); }
   double up = 0;

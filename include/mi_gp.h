@@ -134,7 +134,8 @@ int mi_gp_predict_grad(mi_gp_handle* h, const double* Xnew_dev, int m, double* w
 
 /* tuning knobs (benchmarks / A-B tests), ALL per handle -- nothing here is process-wide:
  *   0  look-ahead: factor the next super-panel on a second stream while the trailing update runs; 0 never, 1 by size
- *      (default: from 20 tile columns = N > 2432 on, where the overlap beats the cross-stream hand-offs), 2 always
+ *      (default: from 20 tile columns = N > 2432 on, where the overlap beats the cross-stream hand-offs -- and from 8 tile
+ *      columns on for problems that run in column mode from the start, option 37), 2 always
  *   2  super-panel width in 128-column tiles (default 0 = by trailing size, options 4-6)
  *   4-6  trailing sizes (tile columns) above which the super-panel is 16 / 8 / 4 tiles wide (below the last: 2);
  *        defaults: never 16, else 8; with look-ahead active, problems of up to 64 tile columns use at most 4
@@ -178,7 +179,15 @@ int mi_gp_predict_grad(mi_gp_handle* h, const double* Xnew_dev, int m, double* w
  *      in-panel updates to the NEXT super-panel's first tile column, level by level, instead of one update of that column
  *      behind the panel (problems of 20 tile columns or more, not the last 8 columns).  Regroups that column's sums; a rule of
  *      the shape alone as well.
- * 8, 14, 16, 18, 19, 21, 24, 26, 27, 29, 30 and 31 only change scheduling (bit-identical results); 20 moves tiles between the two GEMM kernels (same k order); 2, 4-7, 9 regroup sums (agreement to rounding), and so does 0 where
+ *   36 the main stream's update of the next super-panel's other columns in one launch per recursion level of that panel, each with
+ *      its own signal, in steps with at most this many trailing tile columns (default 0 = never: measured slower, N = 4096 1.456 ->
+ *      1.509 ms -- the main stream's launches and signals add up to more than the chain saves); scheduling only
+ *   37 column mode: the last this-many tile columns (default 24; 0: never) are factored column by column -- leaf, strip and one
+ *      k = 256 thin update of the next column on the panel stream; older columns reach a column through k = 128 updates on the
+ *      main stream, a column behind the chain.  Problems of up to that many tile columns run in it from the start, on two
+ *      streams from 8 tile columns on.  Regroups sums (agreement to rounding); a rule of the shape alone: one stream, two
+ *      streams and a batch return the same bits.  N = 2048 0.665 -> 0.619 ms, 3072 0.981 -> 0.920, 4096 1.471 -> 1.443.
+ * 8, 14, 16, 18, 19, 21, 24, 26, 27, 29, 30, 31 and 36 only change scheduling (bit-identical results); 20 moves tiles between the two GEMM kernels (same k order); 2, 4-7, 9, 32-35 and 37 regroup sums (agreement to rounding), and so does 0 where
  * it changes the super-panel width (20 to 60 tile columns).
  * Unknown ids return -1.  (Round 1's options 1, 3, 10-13 -- GEMM variants, hipGraph replay, persistent bulk kernels,
  * exclusive leaf, fused leaf + strip -- are gone with the code they selected.) */

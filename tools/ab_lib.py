@@ -18,13 +18,17 @@ L.LIB_PATH = os.path.abspath(sys.argv[2])
 from andvaranaut_amd import MiGP
 from bench import synth_problem, theta_sequence
 N, d, kern = int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+grad = len(sys.argv) > 6 and sys.argv[6] == "grad"   # spec "N d kernel grad": LML + gradient evaluations
 X, y = synth_problem(N, d, seed=0)
-gp = MiGP(X, y, kern, need_grad=False)
+gp = MiGP(X, y, kern, need_grad=grad)
 th = theta_sequence(d, 8, seed=0)
+if grad:
+    _lml = gp.lml
+    gp.lml = lambda t: gp.lml_grad(t)[0]
 for i in range(3):
     gp.lml(th[i])
 res = []
-reps = 10 if N <= 8192 else 5
+reps = (10 if N <= 8192 else 5) if not grad else (6 if N <= 8192 else 3)
 for rnd in range(5):
     t0 = time.perf_counter()
     for i in range(reps):

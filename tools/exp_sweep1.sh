@@ -1,7 +1,3 @@
 mkdir -p gpurun_out
-O=gpurun_out/r05_sweep5.txt; rm -f $O
-for N in 8192 12288; do
-timeout -k 10 400 python tools/dev_ab_opts.py $N 8 RBF default "38=4" "38=2" "38=1" >> $O 2>&1
-done
-timeout -k 10 400 python tools/dev_ab_opts.py 16384 16 Matern52 default "38=4" "38=2" >> $O 2>&1
-grep median $O
+timeout -k 10 1000 python tools/ab_lib.py "2048 8 RBF grad" "4096 8 RBF grad" "8192 8 RBF grad" "16384 16 Matern52 grad" -- tools/ab/lib_r4.so tools/ab/lib_r5.so > gpurun_out/r05_vs_r04_ab_grad.txt 2>&1
+cat gpurun_out/r05_vs_r04_ab_grad.txt

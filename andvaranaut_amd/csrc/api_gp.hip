@@ -1,7 +1,6 @@
 // Handle-level C-ABI (include/mi_gp.h): covariance assembly -> blocked right-looking Cholesky ->
 // log marginal likelihood.  Replaces what pm.find_MAP / pm.sample evaluate per step through
 // pm.gp.Marginal.marginal_likelihood (gpmcmc.py:321-323, 345, 351).
-#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -986,16 +985,8 @@ static int factor_internal(mi_gp_handle* h, const double* theta, int what) {
     h->theta_host[i] = theta[i];
   }
   const bool prof = h->prof_level >= 1;
-  static const bool host_timing = getenv("MIGP_HOST_TIMING") != nullptr;  // dev aid: enqueue time vs total, on stderr
-  const auto tq0 = std::chrono::steady_clock::now();
   if (int r = run_evaluation(h, what)) return r;
-  const auto tq1 = std::chrono::steady_clock::now();
   HCK(hipStreamSynchronize(h->stream), "stream sync");
-  if (host_timing) {
-    const auto tq2 = std::chrono::steady_clock::now();
-    fprintf(stderr, "[migp] enqueue %.1f us, sync after %.1f us\n", std::chrono::duration<double, std::micro>(tq1 - tq0).count(),
-            std::chrono::duration<double, std::micro>(tq2 - tq1).count());
-  }
   if (prof) {
     float ms;
     (void)hipEventElapsedTime(&ms, h->ev[0], h->ev[1]); h->t_assemble_ms = ms;

@@ -180,3 +180,24 @@ def test_round5_arithmetic_options_agree_to_rounding_and_off_is_the_round4_chain
         assert np.array_equal(single, batch), (o32, o35, o37)
     assert max(vals) - min(vals) <= 1e-11 * abs(ref), vals
     gp.close()
+
+
+@pytest.mark.parametrize("ntc,ragged", [(7, 0), (8, -37), (9, 0), (19, -1), (20, 0), (23, -100), (24, 0), (25, -3), (28, 0), (29, -64), (33, 0)])
+def test_tile_column_counts_around_the_round5_thresholds(ntc, ragged):
+    """One stream below 8 tile columns, column mode from the start up to 24, an entry into it behind one or more super-panels
+    above, extended panels from 20: every boundary of those rules (and ragged last tiles) against the oracle, LML and gradient,
+    and a batch of three against the single entry point."""
+    MiGP, orc = _mods()
+    N, d = 128 * ntc + ragged, 3
+    X, y = orc.synth_problem(N, d, seed=ntc)
+    theta = orc.synth_theta(d)
+    ref, gref = orc.lml_grad(X, y, ["Matern32"], [], theta)
+    gp = MiGP(X, y, "Matern32")
+    v, g = gp.lml_grad(theta)
+    assert abs(v - ref) <= 1e-10 * abs(ref), (N, v, ref)
+    scale = np.maximum(np.abs(gref), 1e-3 * np.max(np.abs(gref)))
+    assert np.max(np.abs(g - gref) / scale) <= 1e-7, (N, g, gref)
+    assert gp.lml(theta) == v
+    th = np.stack([orc.synth_theta(d, kv=1.0 + 0.3 * i) for i in range(3)])
+    assert np.array_equal(gp.lml_batch(th), np.array([gp.lml(t) for t in th]))
+    gp.close()

@@ -1,4 +1,4 @@
-"""Device vs oracle at the BASELINE configs' FULL sizes, one record per leg in profiles/r04_fullsize_parity.json.
+"""Device vs oracle at the BASELINE configs' FULL sizes, one record per leg in profiles/r05_fullsize_parity.json.
 
   python tools/fullsize_parity.py c4       RBF N=65536 d=32: LML, device (single-GPU path) vs oracle           (gpmcmc.py:311-318)
   python tools/fullsize_parity.py c3grad   Matern-5/2 N=16384 d=16: LML + gradient vs oracle.lml_grad             (gpmcmc.py:345,351)

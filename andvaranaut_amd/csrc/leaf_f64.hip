@@ -902,27 +902,16 @@ __device__ __forceinline__ void trsm_strip128_body(const double* __restrict__ mi
   const int wave = tid >> 6;
   const int n = lane & 15, q = lane >> 4;
   const int jb0 = wave, jb1 = 7 - wave;  // jb0 < jb1; k-blocks 0 .. jb1 are needed
-  double* Brow = B + ((long)blk * (16 * RG) + n) * ldb + 4 * q;
-  double2_t a[8][2];  // ONE row group's operands; a k-block's pair is refilled with the next group's as soon as it is consumed
-  auto load_kb = [&](int rg, int kb) {
-    const double* src = Brow + (long)rg * 16 * ldb;
-    a[kb][0] = *reinterpret_cast<const double2_t*>(src + 16 * kb);
-    a[kb][1] = *reinterpret_cast<const double2_t*>(src + 16 * kb + 2);
-  };
-  // RG == 1 (the chain's latency case): the 16 x 128 rows come in as four 1 KB row loads per wave and reach operand order
-  // through LDS (rows 130 doubles apart: a quarter-wave's 16-byte reads then cover all 64 banks once).  Loaded straight into
-  // operand registers -- every quarter-wave touching 16 rows -- the kernel was bound by the texture addresser.
-  __shared__ __attribute__((aligned(16))) double As[RG == 1 ? 16 * 130 : 2];
-  double2_t stage[4];
-  if constexpr (RG == 1) {
+  double2_t a[8][2];  // one row group's operands
+  // The workgroup's 16 RG x 128 rows come in as 1 KB row loads (four per wave and row group) and reach operand order through
+  // LDS (rows 130 doubles apart: a quarter-wave's 16-byte reads then cover all 64 banks once).  Loaded straight into operand
+  // registers -- every quarter-wave touching 16 rows -- the kernel was bound by the texture addresser (round 5; RG > 1 until
+  // then also refilled a group's registers behind their last MFMA and paid a barrier per group for storing in place).
+  __shared__ __attribute__((aligned(16))) double As[RG * 16 * 130];
+  double2_t stage[4 * RG];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      stage[i] = *reinterpret_cast<const double2_t*>(B + ((long)blk * 16 + 4 * wave + i) * ldb + 2 * lane);
-  } else {
-#pragma unroll
-    for (int kb = 0; kb < 8; ++kb)
-      if (kb <= jb1) load_kb(0, kb);
-  }
+  for (int i = 0; i < 4 * RG; ++i)
+    stage[i] = *reinterpret_cast<const double2_t*>(B + ((long)blk * (16 * RG) + 4 * RG * wave + i) * ldb + 2 * lane);
   // M tiles (jb, kb), kb <= jb, in operand order (minv_index): (jb0 + 1) + (jb1 + 1) = 9 tiles, two coalesced 1 KB loads each
   const double* m0 = minv + (long)(jb0 * 8) * 256 + 2 * lane;
   const double* m1 = minv + (long)(jb1 * 8) * 256 + 2 * lane;
@@ -941,28 +930,24 @@ __device__ __forceinline__ void trsm_strip128_body(const double* __restrict__ mi
       b1[kb][1] = *reinterpret_cast<const double2_t*>(m1 + 256 * kb + 128);
     }
   }
-  if constexpr (RG == 1) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<double2_t*>(As + (4 * wave + i) * 130 + 2 * lane) = stage[i];
-    __syncthreads();  // (every wave's rows have left memory: storing to them in place is safe from here on)
-#pragma unroll
-    for (int kb = 0; kb < 8; ++kb) {
-      if (kb <= jb1) {
-        a[kb][0] = *reinterpret_cast<const double2_t*>(As + n * 130 + 16 * kb + 4 * q);
-        a[kb][1] = *reinterpret_cast<const double2_t*>(As + n * 130 + 16 * kb + 4 * q + 2);
-      }
-    }
-  }
+  for (int i = 0; i < 4 * RG; ++i) *reinterpret_cast<double2_t*>(As + (4 * RG * wave + i) * 130 + 2 * lane) = stage[i];
+  __syncthreads();  // (every wave's rows have left memory: storing to them in place is safe from here on)
 #pragma unroll
   for (int rg = 0; rg < RG; ++rg) {
     // Four partial accumulators per output tile, one per MFMA step of a k-block (round 4): a dependent fp64 MFMA follows
     // its predecessor after ~250 cycles but an independent one after 64, and with ONE accumulator per tile the wave that
     // owns column block 7 ran a chain of 32 per row group (8000 of the ~16000 cycles of a one-group strip, and nearly all
     // of a four-group strip's 16 us).  Now the longest chain is 8 deep and the partial sums are added pairwise at the end.
-    // The registers for the partials come from the second operand set of rounds 2-3 (two row groups in flight): a k-block's
-    // operands are refilled with the next group's right behind their last MFMA instead, still a whole MFMA phase ahead.
     const double4_t zero4 = {0.0, 0.0, 0.0, 0.0};
     double4_t p1[4] = {zero4, zero4, zero4, zero4}, p0[4] = {zero4, zero4, zero4, zero4};
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+      if (kb <= jb1) {
+        a[kb][0] = *reinterpret_cast<const double2_t*>(As + (16 * rg + n) * 130 + 16 * kb + 4 * q);
+        a[kb][1] = *reinterpret_cast<const double2_t*>(As + (16 * rg + n) * 130 + 16 * kb + 4 * q + 2);
+      }
+    }
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb) {
       if (kb <= jb1) {
@@ -977,16 +962,8 @@ __device__ __forceinline__ void trsm_strip128_body(const double* __restrict__ mi
         p0[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kb][1].x, b0[kb][1].x, p0[2], 0, 0, 0);
         p0[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kb][1].y, b0[kb][1].y, p0[3], 0, 0, 0);
       }
-      if (rg + 1 < RG && kb <= jb1) load_kb(rg + 1, kb);
     }
     const double4_t x0 = (p0[0] + p0[1]) + (p0[2] + p0[3]), x1 = (p1[0] + p1[1]) + (p1[2] + p1[3]);
-    // every wave's copy of this row group is in registers (its MFMAs consumed it; the next group's loads may still be
-    // in flight, they touch other rows) before anybody overwrites the group
-    if constexpr (RG > 1) {
-      if (rg + 1 < RG) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(16) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-    }
     // D layout: lane holds X[16 (blk RG + rg) + q + 4 r][16 jb + n]
     double* out = B + ((long)blk * (16 * RG) + 16 * rg + q) * ldb + n;
 #pragma unroll

@@ -50,6 +50,8 @@ struct mi_gp_handle {
   int thin_max_wg;                  // option 32: in-panel updates of at most this many 16-row x 128-column slices (and at most thin_max_cols
                                     // tile columns, k <= thin_max_k) run on the thin direct-operand kernel (thin_f64.hip); 0: never
   int thin_max_cols, thin_max_k;    // options 33 / 34
+  int rl_group;                     // option 38: column mode of a BATCH applies the main stream's k = 128 updates to the far columns in
+                                    // k-segmented launches of this many columns (same bits, the trailing matrices read and written once per group)
   int rl_cols;                      // option 37: the last rl_cols tile columns are factored COLUMN BY COLUMN (cholesky(): column mode); 0: never
   int ext_rows;                     // option 35: a super-panel with at most this many tile rows below it also applies its updates to
                                     // the NEXT super-panel's first tile column, level by level (chol_panel's nx); 0: never
@@ -221,6 +223,7 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   h->thin_max_cols = 2;
   h->thin_max_k = 128;
   h->rl_cols = 24;
+  h->rl_group = 8;
   h->ext_rows = 32;
   h->a2_split_cols = 0;
   h->done_col = h->done_slot = -1;
@@ -316,6 +319,7 @@ extern "C" int mi_gp_set_option(mi_gp_handle* h, int what, int value) {
   else if (what == 35) h->ext_rows = value < 0 ? 0 : value;
   else if (what == 36) h->a2_split_cols = value < 0 ? 0 : value;
   else if (what == 37) h->rl_cols = value < 0 ? 0 : value;
+  else if (what == 38) h->rl_group = value < 1 ? 1 : value > 8 ? 8 : value;
   else if (what == 9) h->tail_small = value ? 1 : 0;
   else {
     snprintf(h->err, sizeof(h->err), "mi_gp_set_option: unknown option %d", what);
@@ -379,7 +383,7 @@ static bool thin_shape(const mi_gp_handle* h, int mt, int nc, int kw) {
 // wr (in-panel updates only): raised to the evaluation's epoch once everything queued on `st` before this update is done
 static hipError_t syrk_trapezoid(mi_gp_handle* h, double* A, long lda, int ntr, int r0, int nc, int k0, int kw,
                                  hipStream_t st, int one_per_cu = 0, int tile0 = 0, int tile_cnt = 0, int fc = 0,
-                                 bool in_panel = false, unsigned* wr = nullptr, bool lsw = false) {
+                                 bool in_panel = false, unsigned* wr = nullptr, bool lsw = false, int kflush = 0) {
   if (in_panel && thin_shape(h, ntr - r0, nc, kw))
     return launch_syrk_thin(A + (long)r0 * 128 * lda + (long)k0 * 128, A + (long)r0 * 128 * lda + (long)r0 * 128, lda, ntr - r0, nc,
                             kw * 128, st, h->btp, wr, h->sig_epoch, lsw ? h->dinv_dev + (size_t)h->ntc * MINV_ELEMS : nullptr);
@@ -408,6 +412,7 @@ static hipError_t syrk_trapezoid(mi_gp_handle* h, double* A, long lda, int ntr, 
   p.kmode = 0;
   p.alpha = -1.0;
   p.beta = 1.0;
+  p.kflush = kflush;
   // algorithmic flops (nb*m^2 for the lower-triangle SYRK, 2*nb*rows*cols for the block
   // below it, one y^T row for the folded-in forward solve); the MFMA work issued is slightly larger
   // (full diagonal tiles, a 128-row tile for the y row).
@@ -580,6 +585,8 @@ static hipError_t chol_columns(mi_gp_handle* h, double* A, long lda, int ntr, in
     return se;
   };
   double* lsw0 = h->dinv_dev + (size_t)h->ntc * MINV_ELEMS;
+  const int group = (h->btp && h->btp->nb > 1) ? h->rl_group : 1;
+  int seg0 = cs;  // grouped schedule: first column (k-segment) the columns behind the chain's next one have not had yet
   if (two && t_pending) CKC(t_signal((cs + 1) % 3));  // polled by leaf cs: the index leaf j polls is (j - 2) mod 3 = (j + 1) mod 3
   for (int j = cs; j < ntc; ++j) {
     double* blk = A + (long)j * 128 * lda + (long)j * 128;
@@ -622,8 +629,21 @@ static hipError_t chol_columns(mi_gp_handle* h, double* A, long lda, int ntr, in
     }
     if (t_work) {
       if (sslot >= 0) CKC(hipStreamWaitValue32(T, h->sig_dev + sslot, h->sig_epoch, hipStreamWaitValueGte, 0xffffffffu));
-      CKC(syrk_trapezoid(h, A, lda, ntr, j + 2, ntc - j - 2, j - 1, 1, T));
-      if (two) CKC(t_signal((j - 1) % 3));
+      if (group <= 1) {
+        CKC(syrk_trapezoid(h, A, lda, ntr, j + 2, ntc - j - 2, j - 1, 1, T));
+        if (two) CKC(t_signal((j - 1) % 3));
+      } else {
+        // A batch is bound by the main stream's updates, not by the chain, and a k = 128 update reads and writes the trailing
+        // matrices for 128 columns of k.  Same arithmetic, grouped: the column the chain needs next takes the segments it
+        // has not had yet (k-segmented launch: the tile takes each 128-column partial sum as a launch of its own would), the
+        // columns behind it take `group` segments at a time.  Invariant: every column >= j + 3 has exactly the segments < seg0.
+        CKC(syrk_trapezoid(h, A, lda, ntr, j + 2, 1, seg0, j - seg0, T, 0, 0, 0, 0, false, nullptr, false, j - seg0 > 1 ? 128 : 0));
+        if (two) CKC(t_signal((j - 1) % 3));
+        if (j - seg0 >= group && j + 3 < ntc) {
+          CKC(syrk_trapezoid(h, A, lda, ntr, j + 3, ntc - j - 3, seg0, j - seg0, T, 0, 0, 0, 0, false, nullptr, false, 128));
+          seg0 = j;
+        }
+      }
     }
     if (two && h->u_early && j > cs && (j - cs) % 4 == 0) {
       // gradient evaluations: U = L^-T over the columns that are final (strips <= j - 1), behind the main stream's update

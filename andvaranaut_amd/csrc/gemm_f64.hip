@@ -606,6 +606,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel_s(GemmParams p) {
   if (nchunk > 0) load_frags(0, 0, 0);
   // one chunk c; S = c % 3: LDS buffer consumed; register set (S + 1) % 3 is refilled with chunk c + 4; register set and
   // LDS buffer (S + 2) % 3 take part in the hand-over of chunk c + 2
+  const int kflush_chunks = (p.kflush > 0 && beta != 0.0) ? p.kflush / BKS : 0;
   auto chunk_body = [&](int c, auto Sc) {
     constexpr int sidx = decltype(Sc)::value;
     constexpr int boff = sidx * OPER_S;
@@ -655,6 +656,22 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel_s(GemmParams p) {
     }
     advance(c + 5);
     __builtin_amdgcn_sched_barrier(0);
+    if (kflush_chunks > 0 && (c + 1) % kflush_chunks == 0 && c + 1 < nchunk) {
+      // k-segmented update (GemmParams::kflush): C takes this segment's sum NOW, rounded as a launch of its own would round
+      // it, and the accumulators start the next segment at zero -- one launch then returns the bits of one launch per segment
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            double v = alpha * acc[a][b][r];
+            v += beta * cv[a][b][r];
+            cv[a][b][r] = v;
+          }
+          acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+        }
+    }
     __syncthreads();
   };
   int c = 0;
@@ -687,7 +704,10 @@ static int tile_count(const GemmParams& p) {
 
 
 // launches with fewer 128x128 tiles than p.small_below run on 64x64 tiles (4x the workgroups, 1/4 of the latency)
-bool gemm_uses_small_tiles(const GemmParams& p, int batch) { return tile_count(p) * batch < p.small_below && p.kmode != 2; }
+bool gemm_uses_small_tiles(const GemmParams& p, int batch) {
+  if (p.kflush > 0) return true;  // (the 64x64-tile kernel holds its C tile in registers from the start: only it can flush per k-segment)
+  return tile_count(p) * batch < p.small_below && p.kmode != 2;
+}
 
 // The 128x128-tile kernel runs its tiles in rounds of 512 (two workgroups on each of 256 CUs, 218 us per round at
 // k = 1024): a last round with few tiles costs a whole round (7 % of the nine bulk launches of an N = 16384

@@ -56,6 +56,10 @@ struct GemmParams {
   // panel buffer is laid out this way (one contiguous piece per tile column, broadcast as soon as it is final).  0: one segment.
   int kseg = 0;
   long kseg_stride = 0;
+  // k-segmented UPDATE (kmode 0, beta = 1): every kflush columns of k (a multiple of 16; the driver uses 128) the tile takes the
+  // partial sum, C = beta C + alpha acc rounded there, and the accumulators restart -- the bits of one launch per segment in one
+  // launch, with C read and written once.  Such launches run on the 64x64-tile kernel whatever their size.  0: off.
+  int kflush = 0;
   // set by the launcher for that second launch: 64x64 tile 4 e + quadrant belongs to 128x128 tile sub_base + e of the
   // parent enumeration (sub_mt x sub_nt tiles of 128); -1: off
   int sub_base = -1, sub_mt = 0, sub_nt = 0;

@@ -187,7 +187,10 @@ int mi_gp_predict_grad(mi_gp_handle* h, const double* Xnew_dev, int m, double* w
  *      main stream, a column behind the chain.  Problems of up to that many tile columns run in it from the start, on two
  *      streams from 8 tile columns on.  Regroups sums (agreement to rounding); a rule of the shape alone: one stream, two
  *      streams and a batch return the same bits.  N = 2048 0.665 -> 0.619 ms, 3072 0.981 -> 0.920, 4096 1.471 -> 1.443.
- * 8, 14, 16, 18, 19, 21, 24, 26, 27, 29, 30, 31 and 36 only change scheduling (bit-identical results); 20 moves tiles between the two GEMM kernels (same k order); 2, 4-7, 9, 32-35 and 37 regroup sums (agreement to rounding), and so does 0 where
+ *   38 column mode of a BATCH: the main stream applies its k = 128 updates to the columns behind the chain's next one in
+ *      k-segmented launches of this many columns (default 8; 1: one launch per column as for a single evaluation).  The tile
+ *      takes every 128-column partial sum as a launch of its own would round it: same bits, scheduling only.
+ * 8, 14, 16, 18, 19, 21, 24, 26, 27, 29, 30, 31, 36 and 38 only change scheduling (bit-identical results); 20 moves tiles between the two GEMM kernels (same k order); 2, 4-7, 9, 32-35 and 37 regroup sums (agreement to rounding), and so does 0 where
  * it changes the super-panel width (20 to 60 tile columns).
  * Unknown ids return -1.  (Round 1's options 1, 3, 10-13 -- GEMM variants, hipGraph replay, persistent bulk kernels,
  * exclusive leaf, fused leaf + strip -- are gone with the code they selected.) */

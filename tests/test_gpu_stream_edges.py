@@ -176,8 +176,9 @@ def test_round5_arithmetic_options_agree_to_rounding_and_off_is_the_round4_chain
         assert abs(v - ref) <= 1e-10 * abs(ref), (o32, o35, o37)
         vals.append(v)
         single = np.array([gp.lml(t) for t in th])
-        batch = gp.lml_batch(th)
-        assert np.array_equal(single, batch), (o32, o35, o37)
+        for group in (8, 1, 3):  # option 38: a batch's k-segmented main-stream updates in column mode -- scheduling only
+            gp.set_option(38, group)
+            assert np.array_equal(single, gp.lml_batch(th)), (o32, o35, o37, group)
     assert max(vals) - min(vals) <= 1e-11 * abs(ref), vals
     gp.close()
 

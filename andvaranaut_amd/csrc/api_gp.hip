@@ -197,7 +197,8 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   h->lookahead = 1;
   h->tail_small = 1;
   h->chain_prio = 1;  // N = 8192: 6.06 -> 5.94 ms, N = 16384: 28.11 -> 27.74 ms (interleaved A/B)
-  h->small_below = GemmParams().small_below;
+  h->small_below = 768;  // (1024 until the end of round 5: N = 6144 2.855 -> 2.829 ms, 7168 3.835 -> 3.798, 8192 5.008 -> 4.913, 12288 12.61 -> 12.49 on
+                         // a slow box, same bits; 512: 6144 2.780 but 10240 / 12288 lose; 256 and 1536 lose everywhere)
   h->band_rows = GemmParams().band;
   h->split_tiles = 1536;  // (2048 until the chain got shorter -- stream memory operations, strip kernel: N = 16384 26.21 -> 25.96 ms,
                           // 1024: 26.21, 1280: 26.09, 1792: 26.08; N = 12288 flat)

@@ -50,6 +50,7 @@ struct mi_gp_handle {
   int thin_max_wg;                  // option 32: in-panel updates of at most this many 16-row x 128-column slices (and at most thin_max_cols
                                     // tile columns, k <= thin_max_k) run on the thin direct-operand kernel (thin_f64.hip); 0: never
   int thin_max_cols, thin_max_k;    // options 33 / 34
+  int wide_min;                     // option 39: small-path GEMM launches of at least this many 128x128 tiles run on 64x128 tiles (0: never)
   int rl_group;                     // option 38: column mode of a BATCH applies the main stream's k = 128 updates to the far columns in
                                     // k-segmented launches of this many columns (same bits, the trailing matrices read and written once per group)
   int rl_cols;                      // option 37: the last rl_cols tile columns are factored COLUMN BY COLUMN (cholesky(): column mode); 0: never
@@ -225,6 +226,7 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   h->thin_max_k = 128;
   h->rl_cols = 24;
   h->rl_group = 8;
+  h->wide_min = 0;  // (measured slower than the 64x64-tile kernel as built: profiles/NOTES_r05.md)
   h->ext_rows = 32;
   h->a2_split_cols = 0;
   h->done_col = h->done_slot = -1;
@@ -321,6 +323,7 @@ extern "C" int mi_gp_set_option(mi_gp_handle* h, int what, int value) {
   else if (what == 36) h->a2_split_cols = value < 0 ? 0 : value;
   else if (what == 37) h->rl_cols = value < 0 ? 0 : value;
   else if (what == 38) h->rl_group = value < 1 ? 1 : value > 8 ? 8 : value;
+  else if (what == 39) h->wide_min = value < 0 ? 0 : value;
   else if (what == 9) h->tail_small = value ? 1 : 0;
   else {
     snprintf(h->err, sizeof(h->err), "mi_gp_set_option: unknown option %d", what);
@@ -414,6 +417,7 @@ static hipError_t syrk_trapezoid(mi_gp_handle* h, double* A, long lda, int ntr, 
   p.alpha = -1.0;
   p.beta = 1.0;
   p.kflush = kflush;
+  p.wide_min = h->wide_min;
   // algorithmic flops (nb*m^2 for the lower-triangle SYRK, 2*nb*rows*cols for the block
   // below it, one y^T row for the folded-in forward solve); the MFMA work issued is slightly larger
   // (full diagonal tiles, a 128-row tile for the y row).

@@ -60,6 +60,9 @@ struct GemmParams {
   // partial sum, C = beta C + alpha acc rounded there, and the accumulators restart -- the bits of one launch per segment in one
   // launch, with C read and written once.  Such launches run on the 64x64-tile kernel whatever their size.  0: off.
   int kflush = 0;
+  // launches (and tails of 128x128-tile launches) on the small-tile path with at least this many 128x128 tiles run on 64x128
+  // tiles when they are plain (row-major operands, uniform k, no panel list / k-segments / k-flush); 0: never
+  int wide_min = 0;
   // set by the launcher for that second launch: 64x64 tile 4 e + quadrant belongs to 128x128 tile sub_base + e of the
   // parent enumeration (sub_mt x sub_nt tiles of 128); -1: off
   int sub_base = -1, sub_mt = 0, sub_nt = 0;

@@ -190,7 +190,10 @@ int mi_gp_predict_grad(mi_gp_handle* h, const double* Xnew_dev, int m, double* w
  *   38 column mode of a BATCH: the main stream applies its k = 128 updates to the columns behind the chain's next one in
  *      k-segmented launches of this many columns (default 8; 1: one launch per column as for a single evaluation).  The tile
  *      takes every 128-column partial sum as a launch of its own would round it: same bits, scheduling only.
- * 8, 14, 16, 18, 19, 21, 24, 26, 27, 29, 30, 31, 36 and 38 only change scheduling (bit-identical results); 20 moves tiles between the two GEMM kernels (same k order); 2, 4-7, 9, 32-35 and 37 regroup sums (agreement to rounding), and so does 0 where
+ *   39 GEMM launches on the small-tile path (and tails of 128x128-tile launches) of at least this many 128x128 tiles run on the
+ *      64x128-tile kernel (plain launches only: row-major operands, uniform k); default 0 = never: as built it is slower than
+ *      the 64x64-tile kernel (N = 8192 4.85 -> 5.25 ms at 256, 5.56 at 64).  Same bits.
+ * 8, 14, 16, 18, 19, 21, 24, 26, 27, 29, 30, 31, 36, 38 and 39 only change scheduling (bit-identical results); 20 moves tiles between the two GEMM kernels (same k order); 2, 4-7, 9, 32-35 and 37 regroup sums (agreement to rounding), and so does 0 where
  * it changes the super-panel width (20 to 60 tile columns).
  * Unknown ids return -1.  (Round 1's options 1, 3, 10-13 -- GEMM variants, hipGraph replay, persistent bulk kernels,
  * exclusive leaf, fused leaf + strip -- are gone with the code they selected.) */

@@ -456,7 +456,9 @@ __device__ __forceinline__ void chunk_store(char* __restrict__ lds, unsigned lof
 }
 }  // namespace vs
 
-template <bool A_KMAJOR, bool B_KMAJOR>
+// FLUSH: the k-segmented update (GemmParams::kflush) -- an instantiation of its own, so that the plain kernel keeps the code
+// and the registers it was tuned with (the flush as a run-time branch cost every launch 4 %: N = 16384 25.0 -> 25.9 ms)
+template <bool A_KMAJOR, bool B_KMAJOR, bool FLUSH = false>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel_s(GemmParams p) {
   using vs::BKS; using vs::OPER_S; using vs::NQS; using vs::LDS_S; using vs::TS;
   if (p.hiprio) __builtin_amdgcn_s_setprio(3);  // panel-chain launches: win the SIMD's issue arbitration against bulk waves
@@ -606,7 +608,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel_s(GemmParams p) {
   if (nchunk > 0) load_frags(0, 0, 0);
   // one chunk c; S = c % 3: LDS buffer consumed; register set (S + 1) % 3 is refilled with chunk c + 4; register set and
   // LDS buffer (S + 2) % 3 take part in the hand-over of chunk c + 2
-  const int kflush_chunks = (p.kflush > 0 && beta != 0.0) ? p.kflush / BKS : 0;
+  const int kflush_chunks = FLUSH ? p.kflush / BKS : 1;
   auto chunk_body = [&](int c, auto Sc) {
     constexpr int sidx = decltype(Sc)::value;
     constexpr int boff = sidx * OPER_S;
@@ -656,7 +658,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel_s(GemmParams p) {
     }
     advance(c + 5);
     __builtin_amdgcn_sched_barrier(0);
-    if (kflush_chunks > 0 && (c + 1) % kflush_chunks == 0 && c + 1 < nchunk) {
+    if constexpr (FLUSH) if ((c + 1) % kflush_chunks == 0 && c + 1 < nchunk) {
       // k-segmented update (GemmParams::kflush): C takes this segment's sum NOW, rounded as a launch of its own would round
       // it, and the accumulators start the next segment at zero -- one launch then returns the bits of one launch per segment
 #pragma unroll
@@ -920,7 +922,10 @@ hipError_t launch_gemm_f64(const GemmParams& p_in, int opA_kmajor, int opB_kmajo
     dim3 grid(nwg, 1, batch), block(256);
     // one_per_cu: unused dynamic LDS on top of the 60 KB static image pushes the request over half a CU
     const size_t pad = p.one_per_cu ? LDS_ONE_PER_CU - sizeof(double) * 2 * vs::NBUF * vs::OPER_S : 0;
-    if (!opA_kmajor && !opB_kmajor) gemm_f64_kernel_s<false, false><<<grid, block, pad, stream>>>(q);
+    if (q.kflush > 0) {
+      if (opA_kmajor || opB_kmajor || q.kmode != 0 || q.beta == 0.0 || q.kflush % vs::BKS) return hipErrorInvalidValue;
+      gemm_f64_kernel_s<false, false, true><<<grid, block, pad, stream>>>(q);
+    } else if (!opA_kmajor && !opB_kmajor) gemm_f64_kernel_s<false, false><<<grid, block, pad, stream>>>(q);
     else if (!opA_kmajor && opB_kmajor) gemm_f64_kernel_s<false, true><<<grid, block, pad, stream>>>(q);
     else if (opA_kmajor && opB_kmajor) gemm_f64_kernel_s<true, true><<<grid, block, pad, stream>>>(q);
     else gemm_f64_kernel_s<true, false><<<grid, block, pad, stream>>>(q);
@@ -950,6 +955,8 @@ hipError_t gemm_f64_enable_lds() {
                                      (int)(LDS_ONE_PER_CU - sizeof(double) * 2 * (vw::OPER_A + vw::OPER_B)));
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_kernel_s<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_kernel_s<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_kernel_s<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);
   if (e != hipSuccess) return e;

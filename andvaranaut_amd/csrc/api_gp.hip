@@ -681,6 +681,7 @@ static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int nt
   h->sig_next = 0;
   h->wait_slot = -1;
   h->wait2_col = h->wait2_slot = -1;
+  h->done_col = h->done_slot = -1;
   h->npw = 0;
   if (++h->sig_epoch == 0xffffffffu) {  // (4e9 factorisations on one handle: start over)
     CKE(hipStreamSynchronize(h->stream));

@@ -198,9 +198,7 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   h->lookahead = 1;
   h->tail_small = 1;
   h->chain_prio = 1;  // N = 8192: 6.06 -> 5.94 ms, N = 16384: 28.11 -> 27.74 ms (interleaved A/B)
-  h->small_below = -1;   // auto: 768 tiles below 128 tile columns, 1024 from there on (at N = 16384 the two are level and the narrow
-                         // next-panel updates stay off the bulk kernel's books)  (1024 until the end of round 5: N = 6144 2.855 -> 2.829 ms, 7168 3.835 -> 3.798, 8192 5.008 -> 4.913, 12288 12.61 -> 12.49 on
-                         // a slow box, same bits; 512: 6144 2.780 but 10240 / 12288 lose; 256 and 1536 lose everywhere)
+  h->small_below = GemmParams().small_below;  // (768 looked 1 % better at N = 6144 .. 12288 while the 64x64-tile kernel carried the k-flush branch; without it: level)
   h->band_rows = GemmParams().band;
   h->split_tiles = 1536;  // (2048 until the chain got shorter -- stream memory operations, strip kernel: N = 16384 26.21 -> 25.96 ms,
                           // 1024: 26.21, 1280: 26.09, 1792: 26.08; N = 12288 flat)
@@ -302,7 +300,7 @@ extern "C" int mi_gp_set_option(mi_gp_handle* h, int what, int value) {
   if (what == 0) h->lookahead = value < 0 ? 0 : value > 2 ? 2 : value;
   else if (what == 2) h->cfg.panel_tiles = value;
   else if (what >= 4 && what <= 6) h->w_thr[what - 4] = value;
-  else if (what == 7) h->small_below = value;  // (< 0: by problem size)
+  else if (what == 7) h->small_below = value;
   else if (what == 8) h->lowocc_thr = value;
   else if (what == 14) h->band_rows = value;
   else if (what == 16) h->chain_prio = value;
@@ -402,7 +400,7 @@ static hipError_t syrk_trapezoid(mi_gp_handle* h, double* A, long lda, int ntr, 
   p.tile_cnt = tile_cnt;
   p.fc = fc;
   p.hiprio = (st == h->pstream && h->chain_prio) ? 1 : 0;
-  p.small_below = h->small_below >= 0 ? h->small_below : (h->ntc >= 128 ? 1024 : 768);
+  p.small_below = h->small_below;
   p.tail_small = h->tail_small;
   p.band = h->band_rows;
   p.A = A + (long)r0 * 128 * lda + (long)k0 * 128;
@@ -1085,7 +1083,7 @@ static hipError_t gemm_call(mi_gp_handle* h, int ak, int bk, const double* A, lo
   p.A = A; p.B = B; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.strideA = sA; p.strideB = sB; p.strideC = sC;
   p.mt = mt; p.nt = nt; p.k = k; p.tri = tri; p.kmode = kmode; p.alpha = alpha; p.beta = beta;
-  p.small_below = h->small_below >= 0 ? h->small_below : (h->ntc >= 128 ? 1024 : 768); p.band = h->band_rows; p.tail_small = h->tail_small;
+  p.small_below = h->small_below; p.band = h->band_rows; p.tail_small = h->tail_small;
   if (h->btp) {  // batched evaluation: the problems are the second batch level (zA / zB / zC: the strides of the matrices A, B, C live in)
     p.batch1 = batch;
     p.strideA2 = zA; p.strideB2 = zB; p.strideC2 = zC;
@@ -1442,7 +1440,7 @@ extern "C" int mi_gp_predict_u(mi_gp_handle* h, const double* Xnew_dev, int m, d
   p.lda = ldw; p.ldb = ld; p.ldc = ldw;
   p.strideA = p.strideB = p.strideC = 0;
   p.mt = mp / 128; p.nt = h->ntc; p.k = h->np; p.tri = 0; p.kmode = 4; p.alpha = 1.0; p.beta = 0.0;
-  p.small_below = h->small_below >= 0 ? h->small_below : (h->ntc >= 128 ? 1024 : 768); p.band = h->band_rows; p.tail_small = h->tail_small;
+  p.small_below = h->small_below; p.band = h->band_rows; p.tail_small = h->tail_small;
   HCK(launch_gemm_f64(p, 0, 1, 1, h->stream), "K* U");
   const int nk = h->spec.nkern, d = h->spec.d;
   const double* th = h->theta_host;

@@ -139,7 +139,7 @@ int mi_gp_predict_grad(mi_gp_handle* h, const double* Xnew_dev, int m, double* w
  *   2  super-panel width in 128-column tiles (default 0 = by trailing size, options 4-6)
  *   4-6  trailing sizes (tile columns) above which the super-panel is 16 / 8 / 4 tiles wide (below the last: 2);
  *        defaults: never 16, else 8; with look-ahead active, problems of up to 64 tile columns use at most 4
- *   7  GEMM launches with fewer 128x128 tiles than this run on 64x64 tiles (default -1: 768 below 128 tile columns, 1024 from there on)
+ *   7  GEMM launches with fewer 128x128 tiles than this run on 64x64 tiles (default 1024)
  *   8  trailing size at or below which look-ahead bulk updates run one workgroup per CU (default: always)
  *   9  128x128-tile GEMM launches with uniform k hand the tiles beyond their last full round of 512 to the 64x64-tile
  *      kernel (default 1: a last round with few tiles costs a whole round; sharded N=65536 on one rank 1.52 -> 1.47 s)

@@ -22,7 +22,7 @@ for (m, n, k) in shapes:
     P, C = A[:m, 2048:2048 + k], A[:m, 4096:4096 + n]
     def run():
         r = lib.mi_gp_gemm_f64_tuned(0, 1, m, n, k, -1.0, P.data_ptr(), ld, P.data_ptr(), ld, 1.0, C.data_ptr(), ld, 1, 0,
-                                     SMALL_BELOW, TAIL, BAND, 0, None)
+                                     SMALL_BELOW, TAIL, BAND, int(os.environ.get("ONE_PER_CU", "0")), None)
         assert r == 0
     for _ in range(3):
         run()

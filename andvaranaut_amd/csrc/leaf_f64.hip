@@ -904,7 +904,7 @@ __device__ __forceinline__ void trsm_strip128_body(const double* __restrict__ mi
   const int jb0 = wave, jb1 = 7 - wave;  // jb0 < jb1; k-blocks 0 .. jb1 are needed
   double2_t a[8][2];  // one row group's operands
   // The workgroup's 16 RG x 128 rows come in as 1 KB row loads (four per wave and row group) and reach operand order through
-  // LDS (rows 130 doubles apart: a quarter-wave's 16-byte reads then cover all 64 banks once).  Loaded straight into operand
+  // LDS (rows 130 doubles apart; PMC: ~40 % of the few LDS cycles are still bank conflicts, ~160 cycles per workgroup -- profiles/r05_pmc_lds_conflicts.txt).  Loaded straight into operand
   // registers -- every quarter-wave touching 16 rows -- the kernel was bound by the texture addresser (round 5; RG > 1 until
   // then also refilled a group's registers behind their last MFMA and paid a barrier per group for storing in place).
   __shared__ __attribute__((aligned(16))) double As[RG * 16 * 130];

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void syrk_thin_kernel(ThinArgs g) {
   constexpr int NC = K / 64;
   double2_t a[NC][4][2], b[NC][4][2];
   // SW (k = 128): the workgroup's 16 x 128 rows as four 1 KB row loads per wave, through LDS into operand order (rows 130
-  // doubles apart: conflict-free 16-byte reads) -- as the strip does it
+  // doubles apart) -- as the strip does it
   constexpr int ALD = K + 2;  // (K = 128 or 256: a row's dword stride is 4 mod 64 either way)
   __shared__ __attribute__((aligned(16))) double As[SW ? 16 * ALD : 2];
   double2_t stage[SW ? K / 32 : 1];

@@ -110,6 +110,7 @@ def load():
     lib.mi_gp_predict_u.argtypes = [vp, vp, ci, vp, cl, vp, vp, ci]
     lib.mi_gp_predict_grad.argtypes = [vp, vp, ci, vp, cl, vp, vp, ci, vp, vp]
     lib.mi_gp_set_option.argtypes = [vp, ci, ci]
+    lib.mi_gp_get_option.argtypes = [vp, ci, ip]
     lib.mi_gp_set_profiling.argtypes = [vp, ci]
     lib.mi_gp_timers.argtypes = [vp, dp, ci]
     lib.mi_gp_assemble_block.argtypes = [ci, ci, ip, ip, vp, vp, ci, vp, ci, ci, ci, vp, cl, ci, ci, ci, vp]
@@ -165,6 +166,7 @@ EXPORTS = [
     "mi_gp_predict_u",
     "mi_gp_predict_grad",
     "mi_gp_set_option",
+    "mi_gp_get_option",
     "mi_gp_set_profiling",
     "mi_gp_timers",
     "mi_gp_gemm_f64",

@@ -39,7 +39,6 @@ class MiGP:
         if not torch.cuda.is_available():
             raise RuntimeError("MiGP needs a ROCm GPU: the GP hot path has no CPU implementation")
         self.lib = _lib.load()
-        self._options = {}  # what set_option was called with (get_option)
         X = np.ascontiguousarray(X, dtype=np.float64)
         y = np.ascontiguousarray(np.asarray(y, dtype=np.float64).reshape(-1))
         if X.ndim != 2 or X.shape[0] != y.shape[0]:
@@ -357,11 +356,18 @@ class MiGP:
         """Per-handle tuning knobs (include/mi_gp.h: 0 look-ahead, 2 super-panel width, 7 small-tile threshold,
         8 one-workgroup-per-CU bulk updates, 14 tile order); unknown ids raise."""
         self._check(self.lib.mi_gp_set_option(self.h, int(what), int(value)), "mi_gp_set_option")
-        self._options[int(what)] = int(value)
 
     def get_option(self, what, default=None):
-        """Last value set through set_option on this handle (the library's own defaults are not mirrored: `default`)."""
-        return self._options.get(int(what), default)
+        """Current value of a knob on this handle, the library's own defaults included (mi_gp_get_option; 40: 1 once the handle
+        has switched its cross-stream edges to events by itself).  `default` for ids the library does not know."""
+        out = ctypes.c_int()
+        if self.lib.mi_gp_get_option(self.h, int(what), ctypes.byref(out)) != 0:
+            return default
+        return out.value
+
+    def last_error(self):
+        """Text of the handle's last error or notice (a demotion of the cross-stream edges is reported here once)."""
+        return self.lib.mi_gp_last_error(self.h).decode()
 
     def set_profiling(self, level):
         self.lib.mi_gp_set_profiling(self.h, int(level))

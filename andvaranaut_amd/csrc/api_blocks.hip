@@ -64,10 +64,6 @@ extern "C" int mi_gp_gemm_f64_tuned(int transa, int transb, int m, int n, int k,
   p.strideA = p.strideB = p.strideC = 0;
   p.mt = m / 128; p.nt = n / 128; p.k = k; p.tri = tri; p.kmode = kmode; p.alpha = alpha; p.beta = beta;
   p.small_below = small_below; p.tail_small = tail_small ? 1 : 0; p.band = band; p.one_per_cu = one_per_cu ? 1 : 0;
-  {  // (measurements of the 64x128-tile kernel through this entry: MIGP_WIDE_MIN = GemmParams::wide_min)
-    static const int wide = getenv("MIGP_WIDE_MIN") ? atoi(getenv("MIGP_WIDE_MIN")) : 0;
-    p.wide_min = wide;
-  }
   hipError_t e = launch_gemm_f64(p, transa ? 1 : 0, transb ? 0 : 1, 1, (hipStream_t)stream);
   if (e != hipSuccess) return fail(e, "launch_gemm_f64");
   return 0;

@@ -34,30 +34,27 @@ struct mi_gp_handle {
   unsigned sig_epoch;
   int sig_next;
   int wait_slot;                    // the slot that stands in for wait_ev
-  int pw_col[4], pw_slot[4], npw;   // (a2) in pieces (option 36): the leaf of tile column pw_col[i] ends only once slot pw_slot[i] is written
-  int a2_split_cols;                // option 36: (a2) runs as one launch per recursion level of the next panel from this many trailing columns on
   int wait2_col, wait2_slot;        // the leaf of tile column wait2_col ends only once this slot is written (everything queued on the
                                     // main stream before the super-panel's chain: the first in-panel update behind that leaf writes
                                     // the next super-panel's first column), -1: none
   bool smo_supported;               // hipDeviceAttributeCanUseStreamWaitValue
   int poll_limit_log2;              // option 27: an in-kernel poll gives up after 2^this sleeps (default 22: seconds)
   int test_drop_signal;             // option 28 (tests): the next evaluation leaves one main-stream signal unwritten
+  bool demoted;                     // a poll ran into its limit (or mi_gp_create's probe found kernel dispatch serialised): the edges
+                                    // are events from then on (use_smo = 0) -- mi_gp_get_option(40)
   int u_early_max_s;                // option 30: block-doubling levels of U = L^-T (node sizes up to this many tiles) that start inside the
                                     // factorisation's chain-bound tail on the main stream (gradient evaluations; 0: none)
   int u_early_cols;                 // option 31: ... from this many trailing tile columns on, and at most this many new columns per step
   bool u_early;                     // this evaluation takes part (set by enqueue_all)
   int u_leaf_done, u_node_done[12]; // tile columns whose leaf block of U is done / full nodes done per level
-  int thin_max_wg;                  // option 32: in-panel updates of at most this many 16-row x 128-column slices (and at most thin_max_cols
-                                    // tile columns, k <= thin_max_k) run on the thin direct-operand kernel (thin_f64.hip); 0: never
-  int thin_max_cols, thin_max_k;    // options 33 / 34
-  int wide_min;                     // option 39: small-path GEMM launches of at least this many 128x128 tiles run on 64x128 tiles (0: never)
+  int thin_max_wg;                  // option 32: in-panel updates of at most this many 16-row x 128-column slices (k = 128, at most
+                                    // THIN_MAX_COLS tile columns) run on the thin kernel (thin_f64.hip); 0: never
   int rl_group;                     // option 38: column mode of a BATCH applies the main stream's k = 128 updates to the far columns in
                                     // k-segmented launches of this many columns (same bits, the trailing matrices read and written once per group)
   int rl_cols;                      // option 37: the last rl_cols tile columns are factored COLUMN BY COLUMN (cholesky(): column mode); 0: never
   int ext_rows;                     // option 35: a super-panel with at most this many tile rows below it also applies its updates to
                                     // the NEXT super-panel's first tile column, level by level (chol_panel's nx); 0: never
   int done_col, done_slot;          // the update behind the strip of tile column done_col raises this slot ("super-panel done")
-  int a2_low;                       // option 29: the main stream's next-panel update (a2) runs one workgroup per CU (-1, the default: up to 48 tile columns)
   int use_smo;                      // option 26: 0 events, 1 runtime stream memory operations, 2 (default) the panel stream's
                                     // halves folded into one-lane launches of the library / the end of a leaf
   // tuning options (mi_gp_set_option), all per handle
@@ -155,6 +152,33 @@ static void release_handle(mi_gp_handle* h) {
   delete h;
 }
 
+// The default edges (option 26 = 2) enqueue a poll on the panel stream AHEAD of the main-stream write it waits for.  That ends
+// only through its limit where kernel dispatch is serialised: rocprofv3 --pmc, AMD_SERIALIZE_KERNEL / HIP_LAUNCH_BLOCKING, a
+// debugger.  One probe at creation -- a one-lane poll on the panel stream with a short limit (2^14 sleeps: a few ms), the write
+// behind it on the main stream -- finds that out before an evaluation can stall for seconds; such a handle uses events
+// (gpmcmc.py:331-339: the reference's evaluations never fail for reasons of scheduling).  ~40 us where dispatch is concurrent.
+static hipError_t probe_dispatch(mi_gp_handle* h) {
+  hipError_t e = hipMemset(h->info_dev, 0x7f, sizeof(int) * 4);
+  // (both streams have launched before: the probe does not time the first launch's code-object load)
+  if (e == hipSuccess) e = launch_signal_write_wait(h->sig_dev + SIG_SLOTS - 1, nullptr, 0u, h->info_dev, h->pstream);
+  if (e == hipSuccess) e = launch_signal_write_wait(h->sig_dev + SIG_SLOTS - 1, nullptr, 0u, h->info_dev, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->pstream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (e == hipSuccess) e = launch_signal_write_wait(nullptr, h->sig_dev + SIG_SLOTS - 1, 1u, h->info_dev, h->pstream, 1, 0, 14);
+  if (e == hipSuccess) e = launch_signal_write_wait(h->sig_dev + SIG_SLOTS - 1, nullptr, 1u, h->info_dev, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->pstream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  int info = 0;
+  if (e == hipSuccess) e = hipMemcpy(&info, h->info_dev, sizeof(int), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemset(h->sig_dev + SIG_SLOTS - 1, 0, sizeof(unsigned));
+  if (e == hipSuccess && info == SIGNAL_TIMEOUT_INFO) {
+    h->use_smo = 0;
+    h->demoted = true;
+    snprintf(h->err, sizeof(h->err), "kernel dispatch is serialised on this device: cross-stream edges are events (option 26 = 0)");
+  }
+  return e;
+}
+
 extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   if (!cfg || !out) { set_global_error("mi_gp_create: null argument"); return -1; }
   if (cfg->n <= 0 || cfg->d <= 0 || cfg->nkern <= 0 || cfg->nkern > MAX_KERN) {
@@ -219,15 +243,11 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   }
   h->poll_limit_log2 = 22;
   h->test_drop_signal = 0;
-  h->a2_low = -1;
+  h->demoted = false;
   h->thin_max_wg = 2048;
-  h->thin_max_cols = 2;
-  h->thin_max_k = 128;
   h->rl_cols = 24;
   h->rl_group = 8;
-  h->wide_min = 0;  // (measured slower than the 64x64-tile kernel as built: profiles/NOTES_r05.md)
   h->ext_rows = 32;
-  h->a2_split_cols = 0;
   h->done_col = h->done_slot = -1;
   h->u_early_max_s = 16;
   h->u_early_cols = 48;
@@ -236,7 +256,6 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   h->sig_next = 0;
   h->wait_slot = -1;
   h->wait2_col = h->wait2_slot = -1;
-  h->npw = 0;
   // round-2 A/B (tools/dev_ab_opts.py, interleaved in one process): bulk updates at one workgroup per CU whenever the
   // panel chain runs beside them (N = 16384: 29.99 -> 28.97 ms) and 8-tile super-panels at every size (N = 2048 1.045 ->
   // 1.017 ms, 4096 2.470 -> 2.388, 8192 6.417 -> 6.348, 16384 28.59 -> 28.39 against the 8 / 4 split of round 1)
@@ -262,6 +281,7 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   if (e == hipSuccess) e = assemble_enable_lds();
   if (e == hipSuccess) e = gemm_f64_enable_lds();
   if (e == hipSuccess) e = leaf_enable_lds();
+  if (e == hipSuccess && h->use_smo >= 2) e = probe_dispatch(h);
   if (e != hipSuccess) {
     char msg[200];
     snprintf(msg, sizeof(msg), "mi_gp_create: %s", hipGetErrorString(e));
@@ -309,24 +329,63 @@ extern "C" int mi_gp_set_option(mi_gp_handle* h, int what, int value) {
   else if (what == 20) h->merge_min_tiles = value;
   else if (what == 21) h->single_below = value;
   else if (what == 24) h->asm_split = value ? 1 : 0;
-  else if (what == 26) h->use_smo = !h->smo_supported ? 0 : value < 0 ? 0 : value > 2 ? 2 : value;
+  else if (what == 26) {
+    h->use_smo = !h->smo_supported ? 0 : value < 0 ? 0 : value > 2 ? 2 : value;
+    if (h->use_smo != 0) h->demoted = false;  // (the caller asks for polls again: the next time-out demotes again)
+  }
   else if (what == 27) h->poll_limit_log2 = value < 4 ? 4 : value > 30 ? 30 : value;
-  else if (what == 28) h->test_drop_signal = value ? 1 : 0;
-  else if (what == 29) h->a2_low = value < 0 ? -1 : value ? 1 : 0;
+  else if (what == 28) {
+    // (with option 26 = 1 the waiter is a runtime hipStreamWaitValue32 without a limit: the hook would hang the process)
+    if (value && h->use_smo < 2) {
+      snprintf(h->err, sizeof(h->err), "mi_gp_set_option: option 28 needs option 26 = 2 (a bounded in-kernel poll)");
+      return -1;
+    }
+    h->test_drop_signal = value ? 1 : 0;
+  }
   else if (what == 30) h->u_early_max_s = value < 0 ? 0 : value;
   else if (what == 31) h->u_early_cols = value < 8 ? 8 : value;
   else if (what == 32) h->thin_max_wg = value < 0 ? 0 : value;
-  else if (what == 33) h->thin_max_cols = value < 1 ? 1 : value;
-  else if (what == 34) h->thin_max_k = value;
   else if (what == 35) h->ext_rows = value < 0 ? 0 : value;
-  else if (what == 36) h->a2_split_cols = value < 0 ? 0 : value;
   else if (what == 37) h->rl_cols = value < 0 ? 0 : value;
   else if (what == 38) h->rl_group = value < 1 ? 1 : value > 8 ? 8 : value;
-  else if (what == 39) h->wide_min = value < 0 ? 0 : value;
   else if (what == 9) h->tail_small = value ? 1 : 0;
   else {
     snprintf(h->err, sizeof(h->err), "mi_gp_set_option: unknown option %d", what);
     return -1;
+  }
+  return 0;
+}
+
+// current value of a knob (the library's own defaults included); 40: 1 once the handle has demoted its edges to events
+extern "C" int mi_gp_get_option(mi_gp_handle* h, int what, int* value) {
+  if (!h || !value) return -1;
+  switch (what) {
+    case 0: *value = h->lookahead; break;
+    case 2: *value = h->cfg.panel_tiles; break;
+    case 4: case 5: case 6: *value = h->w_thr[what - 4]; break;
+    case 7: *value = h->small_below; break;
+    case 8: *value = h->lowocc_thr; break;
+    case 9: *value = h->tail_small; break;
+    case 14: *value = h->band_rows; break;
+    case 16: *value = h->chain_prio; break;
+    case 18: *value = h->split_tiles; break;
+    case 19: *value = h->split_min_rest; break;
+    case 20: *value = h->merge_min_tiles; break;
+    case 21: *value = h->single_below; break;
+    case 24: *value = h->asm_split; break;
+    case 26: *value = h->use_smo; break;
+    case 27: *value = h->poll_limit_log2; break;
+    case 28: *value = h->test_drop_signal; break;
+    case 30: *value = h->u_early_max_s; break;
+    case 31: *value = h->u_early_cols; break;
+    case 32: *value = h->thin_max_wg; break;
+    case 35: *value = h->ext_rows; break;
+    case 37: *value = h->rl_cols; break;
+    case 38: *value = h->rl_group; break;
+    case 40: *value = h->demoted ? 1 : 0; break;
+    default:
+      snprintf(h->err, sizeof(h->err), "mi_gp_get_option: unknown option %d", what);
+      return -1;
   }
   return 0;
 }
@@ -378,18 +437,19 @@ static hipError_t prof_gemm(mi_gp_handle* h, const GemmParams& p, int ak, int bk
 // trapezoid update  A[r0:, c0:c0+nc] -= P P_c^T  with P = A[r0:, k0:k0+kw] (tile units)
 // In-panel updates only (their shapes do not depend on the schedule), by SHAPE alone -- not the batch size, not a scheduling
 // option: a batch returns the single evaluation's bits, and so does every schedule.
+constexpr int THIN_MAX_COLS = 2;  // (the strip in front of such an update hands it its B operand in operand order: 2 x 128 rows)
 static bool thin_shape(const mi_gp_handle* h, int mt, int nc, int kw) {
-  return h->thin_max_wg > 0 && nc <= h->thin_max_cols && kw * 128 <= h->thin_max_k && syrk_thin_supported(kw * 128) &&
-         (long)mt * 8 * nc <= h->thin_max_wg;
+  return h->thin_max_wg > 0 && nc <= THIN_MAX_COLS && kw == 1 && (long)mt * 8 * nc <= h->thin_max_wg;
 }
 
 // wr (in-panel updates only): raised to the evaluation's epoch once everything queued on `st` before this update is done
 static hipError_t syrk_trapezoid(mi_gp_handle* h, double* A, long lda, int ntr, int r0, int nc, int k0, int kw,
                                  hipStream_t st, int one_per_cu = 0, int tile0 = 0, int tile_cnt = 0, int fc = 0,
                                  bool in_panel = false, unsigned* wr = nullptr, bool lsw = false, int kflush = 0) {
-  if (in_panel && thin_shape(h, ntr - r0, nc, kw))
+  // (lsw: the strip in front of this update has written its first rows in operand order -- chol_panel decides both by the same rule)
+  if (in_panel && lsw && thin_shape(h, ntr - r0, nc, kw))
     return launch_syrk_thin(A + (long)r0 * 128 * lda + (long)k0 * 128, A + (long)r0 * 128 * lda + (long)r0 * 128, lda, ntr - r0, nc,
-                            kw * 128, st, h->btp, wr, h->sig_epoch, lsw ? h->dinv_dev + (size_t)h->ntc * MINV_ELEMS : nullptr);
+                            kw * 128, st, h->btp, wr, h->sig_epoch, h->dinv_dev + (size_t)h->ntc * MINV_ELEMS);
   if (wr != nullptr) {  // (the 64x64-tile kernel has no such hook: a one-lane launch in front of it)
     hipError_t we = launch_signal_write_wait(wr, nullptr, h->sig_epoch, h->info_dev, st);
     if (we != hipSuccess) return we;
@@ -416,7 +476,6 @@ static hipError_t syrk_trapezoid(mi_gp_handle* h, double* A, long lda, int ntr, 
   p.alpha = -1.0;
   p.beta = 1.0;
   p.kflush = kflush;
-  p.wide_min = h->wide_min;
   // algorithmic flops (nb*m^2 for the lower-triangle SYRK, 2*nb*rows*cols for the block
   // below it, one y^T row for the folded-in forward solve); the MFMA work issued is slightly larger
   // (full diagonal tiles, a 128-row tile for the y row).
@@ -450,13 +509,8 @@ static hipError_t chol_panel(mi_gp_handle* h, double* A, long lda, int ntr, int 
     const bool waits2 = c0 == h->wait2_col && h->wait2_slot >= 0 && h->use_smo >= 2;
     const bool folded = waits2 || (waits && h->wait_slot >= 0 && h->use_smo >= 2);
     if (c0 == h->wait2_col) h->wait2_col = -1;
-    // (a2) in pieces: this leaf's poll is for the piece the update behind its strip reads (written before wait2's slot as well)
-    int pslot = -1;
-    for (int i = 0; i < h->npw; ++i)
-      if (h->pw_col[i] == c0) pslot = h->pw_slot[i];
     e = launch_potrf_leaf128(blk, lda, dinv, c0 * 128, h->info_dev, st, m == 128 ? blk + 128 * lda : nullptr, h->btp,
-                             waits2 ? h->sig_dev + h->wait2_slot : folded ? h->sig_dev + h->wait_slot
-                                                                 : pslot >= 0 ? h->sig_dev + pslot : nullptr,
+                             waits2 ? h->sig_dev + h->wait2_slot : folded ? h->sig_dev + h->wait_slot : nullptr,
                              h->sig_epoch, h->poll_limit_log2);
     if (e == hipSuccess && m > 128)
       e = launch_trsm_strip128(dinv, blk + 128 * lda, lda, m, st, h->btp, h->btp ? h->btp->sK : 0, sw ? lsw : nullptr, 8 * fol);
@@ -664,7 +718,14 @@ static int lookahead_min_tiles(const mi_gp_handle* h, int ntc) {
   return (h->rl_cols > 0 && ntc <= h->rl_cols) ? COLUMN_MODE_MIN_TILES : LOOKAHEAD_MIN_TILES;
 }
 
+static hipError_t cholesky_enqueue(mi_gp_handle* h, double* A, long lda, int ntr, int ntc);
 static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int ntc) {
+  const hipError_t e = cholesky_enqueue(h, A, lda, ntr, ntc);
+  h->test_drop_signal = 0;  // (option 28 is for ONE evaluation, whether or not its schedule had the edge the hook drops)
+  return e;
+}
+
+static hipError_t cholesky_enqueue(mi_gp_handle* h, double* A, long lda, int ntr, int ntc) {
   // A batched evaluation (blockIdx.z = problem) carries nb times the work per launch, so the look-ahead pays from smaller
   // problems on (nb = 8: N = 2560 +5 %, 3072 +10 %, 4096 +7 %; nb = 2 from 3072 on).  The super-panel widths stay those of
   // the single evaluation of the same size, so that a batch returns the single entry points' bits.
@@ -680,7 +741,6 @@ static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int nt
   h->wait_slot = -1;
   h->wait2_col = h->wait2_slot = -1;
   h->done_col = h->done_slot = -1;
-  h->npw = 0;
   if (++h->sig_epoch == 0xffffffffu) {  // (4e9 factorisations on one handle: start over)
     CKE(hipStreamSynchronize(h->stream));
     CKE(hipStreamSynchronize(h->pstream));
@@ -850,30 +910,13 @@ static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int nt
         CKE(syrk_trapezoid(h, A, lda, ntr, n1, 1, J, w, P));
       }
       if (wn > 1) {
-        // (option 29 = 1 runs it one workgroup per CU: the chain's next leaf needs a CU to itself, and with two 64x64-tile
-        // workgroups on every CU none empties before this grid drains -- the first leaf of a super-panel waits 70-160 us at
-        // N = 8192.  Measured: the update itself then takes so much longer that N >= 8192 loses 1.5-2 % (the chain waits for
-        // THIS launch at those steps, not for the leaf) and N <= 6144 gains 0.7-1 %: by default on up to 48 tile columns.)
-        const int a2low = h->a2_low < 0 ? (ntc <= 48 ? 1 : 0) : h->a2_low;
-        h->npw = 0;
-        if (h->use_smo >= 2 && !h->test_drop_signal && wn > 2 && (wn & (wn - 1)) == 0 && ntc - n1 <= h->a2_split_cols &&
-            h->sig_next + 4 <= SIG_SLOTS) {  // (a power of two: the pieces are the recursion's halves)
-          // (a2) in PIECES, one per recursion level of the next panel (columns n1 + 1 | n1 + 2 .. 3 | n1 + 4 .. 7 | ...), each
-          // with its own signal: the in-panel update behind leaf n1 + 2^p - 1 reads piece p's columns only, so the chain's
-          // first leaf polls for ONE column's update (~20 us at N = 4096, hidden behind the leaf) instead of all wn - 1 (40 us).
-          // The same tiles on the same kernel: scheduling only.
-          for (int lo = 1; lo < wn; lo *= 2) {
-            const int cnt = (2 * lo <= wn ? 2 * lo : wn) - lo;
-            CKE(syrk_trapezoid(h, A, lda, ntr, n1 + lo, cnt, J, w, T, a2low));
-            const int slot = signal_from(h, T, &e);
-            if (e != hipSuccess) return e;
-            h->pw_col[h->npw] = n1 + lo - 1;
-            h->pw_slot[h->npw] = slot;
-            ++h->npw;
-          }
-        } else {
+        // One workgroup per CU for problems of up to 48 tile columns: the chain's next leaf needs a CU to itself, and with two
+        // 64x64-tile workgroups on every CU none empties before this grid drains (the first leaf of a super-panel waits 70-160 us
+        // at N = 8192).  Beyond that the update itself takes so much longer at half occupancy that N >= 8192 loses 1.5-2 % (the
+        // chain waits for THIS launch at those steps, not for the leaf); N <= 6144 gains 0.7-1 %.  Scheduling only.
+        const int a2low = ntc <= 48 ? 1 : 0;
         CKE(syrk_trapezoid(h, A, lda, ntr, n1 + 1, wn - 1, J, w, T, a2low));
-        if (h->test_drop_signal && h->use_smo && h->sig_next < SIG_SLOTS) {
+        if (h->test_drop_signal && h->use_smo >= 2 && h->sig_next < SIG_SLOTS) {
           // test hook (option 28): this edge's slot is never written -- the panel stream's poll has to give up
           h->test_drop_signal = 0;
           h->wait_slot = h->sig_next++;
@@ -887,7 +930,6 @@ static hipError_t cholesky(mi_gp_handle* h, double* A, long lda, int ntr, int nt
           CKE(hipEventRecord(h->wait_ev, T));
         }
         h->wait_col = n1;
-        }
       }
     } else if (wn - nx_cur > 0) {
       CKE(syrk_trapezoid(h, A, lda, ntr, n1 + nx_cur, wn - nx_cur, J, w, T));
@@ -999,6 +1041,24 @@ static int run_evaluation(mi_gp_handle* h, int what) {
   return enqueue_all(h, what, prof);
 }
 
+// A poll of the last evaluation ran into its limit: the factor is unsynchronised garbage.  The reference's evaluations never
+// fail for reasons of scheduling (a failed one is swallowed inside the optimiser loop, gpmcmc.py:331-339), so the handle gives
+// up the protocol that needs concurrent dispatch -- polls enqueued ahead of the writes they wait for -- for event edges, says
+// so once through mi_gp_last_error, and the caller's loop evaluates the same theta again (attempt 1).  A second time-out (event
+// edges have no polls: the test hook, or a caller who re-armed option 26 in between) is the caller's error -2.
+static int poll_timeout(mi_gp_handle* h, int attempt) {
+  HCK(hipStreamSynchronize(h->pstream), "panel stream sync");  // (its remaining launches ran through: every later poll gave up at once)
+  if (attempt == 0 && h->use_smo != 0) {
+    h->use_smo = 0;
+    h->demoted = true;
+    snprintf(h->err, sizeof(h->err), "a cross-stream signal was not seen within its poll limit: this handle's cross-stream edges are "
+                                     "events from now on (option 26 = 0), the evaluation was repeated");
+    return 0;
+  }
+  snprintf(h->err, sizeof(h->err), "a cross-stream signal of the factorisation was not seen within its poll limit");
+  return -2;
+}
+
 static int factor_internal(mi_gp_handle* h, const double* theta, int what) {
   h->factored = false;
   h->have_kinv = false;
@@ -1010,8 +1070,12 @@ static int factor_internal(mi_gp_handle* h, const double* theta, int what) {
     h->theta_host[i] = theta[i];
   }
   const bool prof = h->prof_level >= 1;
-  if (int r = run_evaluation(h, what)) return r;
-  HCK(hipStreamSynchronize(h->stream), "stream sync");
+  for (int attempt = 0;; ++attempt) {
+    if (int r = run_evaluation(h, what)) return r;
+    HCK(hipStreamSynchronize(h->stream), "stream sync");
+    if ((int)h->out_host[3] != SIGNAL_TIMEOUT_INFO) break;
+    if (int r = poll_timeout(h, attempt)) return r;
+  }
   if (prof) {
     float ms;
     (void)hipEventElapsedTime(&ms, h->ev[0], h->ev[1]); h->t_assemble_ms = ms;
@@ -1037,10 +1101,6 @@ static int factor_internal(mi_gp_handle* h, const double* theta, int what) {
     }
   }
   const int info = (int)h->out_host[3];  // forwarded by lml_reduce_kernel (reset by set_yrows_kernel)
-  if (info == SIGNAL_TIMEOUT_INFO) {
-    snprintf(h->err, sizeof(h->err), "a cross-stream signal of the factorisation was not seen within its poll limit");
-    return -2;
-  }
   if (info != 0x7f7f7f7f) return info;  // 1-based index of the first bad pivot
   return 0;
 }
@@ -1321,10 +1381,21 @@ static int batch_internal(mi_gp_handle* h, int k, const double* thetas, int what
   h->btp = &h->bt;
   const int prof0 = h->prof_level;
   h->prof_level = 0;
-  int r = run_evaluation(h, what);
-  if (r == 0) {
-    const hipError_t e = hipStreamSynchronize(h->stream);
-    if (e != hipSuccess) r = hfail(h, e, "stream sync");
+  int r = 0;
+  for (int attempt = 0;; ++attempt) {
+    r = run_evaluation(h, what);
+    if (r == 0) {
+      const hipError_t e = hipStreamSynchronize(h->stream);
+      if (e != hipSuccess) r = hfail(h, e, "stream sync");
+    }
+    if (r != 0) break;
+    // a cross-stream poll that gave up leaves unsynchronised data behind in EVERY problem: the whole batch is evaluated again
+    // with event edges (poll_timeout), or fails as a whole
+    bool timed_out = false;
+    for (int p = 0; p < k; ++p) timed_out = timed_out || (int)h->out_host[16 * p + 3] == SIGNAL_TIMEOUT_INFO;
+    if (!timed_out) break;
+    r = poll_timeout(h, attempt);
+    if (r != 0) break;
   }
   h->prof_level = prof0;
   h->btp = nullptr;
@@ -1334,14 +1405,6 @@ static int batch_internal(mi_gp_handle* h, int k, const double* thetas, int what
   h->out_host = out0; h->theta_host = thost0; h->info_dev = info0;
   h->lr_part_dev = lrp0; h->lr_sync_dev = lrs0;
   if (r != 0) return r;
-  // a cross-stream poll that gave up leaves unsynchronised data behind in EVERY problem: the whole batch fails (round 4
-  // reported such a batch as k non-positive-definite points)
-  for (int p = 0; p < k; ++p) {
-    if ((int)h->b_out_host[16 * p + 3] == SIGNAL_TIMEOUT_INFO) {
-      snprintf(h->err, sizeof(h->err), "a cross-stream signal of the batched factorisation was not seen within its poll limit");
-      return -2;
-    }
-  }
   for (int p = 0; p < k; ++p) {
     const int info = (int)h->b_out_host[16 * p + 3];
     const bool ok = info == 0x7f7f7f7f;

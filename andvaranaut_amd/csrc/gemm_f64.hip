@@ -697,158 +697,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel_s(GemmParams p) {
 }
 
 
-// ---------------------------------------------------------------------------------------------
-// 64x128 tiles (round 5): 64 rows x 128 columns per 256-thread workgroup (4 waves as 2 x 2, 32 x 64 per wave)
-// for the launches that are too small for rounds of 128x128 tiles but throughput-bound all the same (the bulk updates of
-// mid-size problems, the next-panel updates, the tails of 128x128-tile launches).  Against the 64x64-tile kernel: 0.094 B/flop
-// from L2 instead of 0.125, six fragment reads per eight MFMAs instead of four per four, half as many workgroups.  Row-major
-// operands, uniform k, no panel list / k-segments / k-flush -- everything else stays on the 64x64-tile kernel.  Per element the
-// k order and the MFMA accumulation are those of the other two kernels: same bits.
-// Two LDS buffers per operand (three would be 86 KB: the k-major rows need their 16 doubles of padding, and two workgroups
-// have to fit a CU), two register sets: chunk c + 3 is requested at the end of chunk c, written to LDS at the end of chunk
-// c + 2; the first fragments of a chunk are read behind its barrier (the other workgroup's waves fill that round trip --
-// which is why launches of few workgroups stay on the 64x64-tile kernel with its third buffer).
-// Workgroup b is half (b & 1: rows 0..63 / 64..127) of 128x128 tile sub_base + (b >> 1) of the parent enumeration.
-namespace vw {
-constexpr int TM = 64, TN = 128, BKW = 16;
-constexpr int LDA_W = 80, LDB_W = 144;               // k-major LDS rows: 64 + 16 and 128 + 16 doubles
-constexpr int OPER_A = BKW * LDA_W, OPER_B = BKW * LDB_W;
-constexpr int NQA = 2, NQB = 4;                      // 32 rows per pass of the 256 threads
-}  // namespace vw
-
-__global__ __launch_bounds__(256, 2) void gemm_f64_kernel_w(GemmParams p) {
-  using namespace vw;
-  if (p.hiprio) __builtin_amdgcn_s_setprio(3);
-  __shared__ __attribute__((aligned(16))) double smem_w[2 * (OPER_A + OPER_B)];  // 57344 B
-  double* As = smem_w;
-  double* Bs = smem_w + 2 * OPER_A;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  int bid = (int)blockIdx.x;
-  {
-    const int nblk = (int)gridDim.x, x = bid & 7, q = nblk >> 3, r = nblk & 7;
-    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
-  }
-  int pti, ptj;
-  const int pidx = p.sub_base + (bid >> 1), half = bid & 1;
-  if (p.fc > 0) tile_from_index_fc(p.sub_mt, p.sub_nt, p.fc, p.band, pidx, pti, ptj);
-  else if (p.band > 0 && p.tri) tile_from_index_banded(p.tri, p.sub_mt, p.sub_nt, pidx, p.band, pti, ptj);
-  else tile_from_index(p.tri, p.sub_nt, pidx, pti, ptj);
-  const bool upper_of_diag = p.tri && pti == ptj && half == 0;  // rows 0..63 of a diagonal tile: columns 64..127 lie above the diagonal
-  const int i0 = (2 * pti + half) * TM, j0 = ptj * TN;
-  const long z1 = p.batch1 > 0 ? (long)(blockIdx.z % p.batch1) : (long)blockIdx.z, z2 = p.batch1 > 0 ? (long)(blockIdx.z / p.batch1) : 0;
-  const double* A = p.A + z1 * p.strideA + z2 * p.strideA2;
-  const double* B = p.B + z1 * p.strideB + z2 * p.strideB2;
-  double* C = p.C + z1 * p.strideC + z2 * p.strideC2;
-
-  double4_t acc[2][4];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
-
-  const int nchunk = p.k / BKW;
-  // coalesced row-major loads: eight consecutive lanes fetch one row's 128-byte chunk segment; k-major LDS image with the
-  // column XOR-swizzled by the k pair (as vs::chunk_offsets)
-  const int kc = tid & 7, row = tid >> 3;
-  const unsigned gA = (unsigned)((row * p.lda + 2 * kc) * 8), gB = (unsigned)((row * p.ldb + 2 * kc) * 8);
-  const unsigned lA = (unsigned)(((2 * kc) * LDA_W + (row ^ (2 * kc))) * 8), lB = (unsigned)(((2 * kc) * LDB_W + (row ^ (2 * kc))) * 8);
-  const long sA = 32 * p.lda * 8, sB = 32 * p.ldb * 8;
-  const char* Ag = reinterpret_cast<const char*>(A + (long)i0 * p.lda);
-  const char* Bg = reinterpret_cast<const char*>(B + (long)j0 * p.ldb);
-  char* Asb = reinterpret_cast<char*>(As);
-  char* Bsb = reinterpret_cast<char*>(Bs);
-  double2_t ra[2][NQA], rb[2][NQB];
-  int next = 0;  // chunk the operand pointers point at
-  auto load_ab = [&](int set) {  // chunk `next` (beyond the last: a redundant reload of the last one, never consumed)
-#pragma unroll
-    for (int q = 0; q < NQA; ++q) ra[set][q] = *reinterpret_cast<const double2_t*>(Ag + q * sA + gA);
-#pragma unroll
-    for (int q = 0; q < NQB; ++q) rb[set][q] = *reinterpret_cast<const double2_t*>(Bg + q * sB + gB);
-    ++next;
-    const long st = next < nchunk ? (long)BKW * 8 : 0;
-    Ag += st;
-    Bg += st;
-  };
-  auto store_ab = [&](int buf, int set) {
-    char* la = Asb + buf * OPER_A * 8 + lA;
-    char* lb = Bsb + buf * OPER_B * 8 + lB;
-#pragma unroll
-    for (int q = 0; q < NQA; ++q) {
-      *reinterpret_cast<double*>(la + q * (32 * 8)) = ra[set][q].x;
-      *reinterpret_cast<double*>(la + q * (32 * 8) + LDA_W * 8) = ra[set][q].y;
-    }
-#pragma unroll
-    for (int q = 0; q < NQB; ++q) {
-      *reinterpret_cast<double*>(lb + q * (32 * 8)) = rb[set][q].x;
-      *reinterpret_cast<double*>(lb + q * (32 * 8) + LDB_W * 8) = rb[set][q].y;
-    }
-  };
-  if (nchunk > 0) {
-    load_ab(0);       // chunk 0
-    load_ab(1);       // chunk 1
-    store_ab(0, 0);
-    load_ab(0);       // chunk 2
-  }
-  const int kq = lane >> 4, l15 = lane & 15;
-  const double alpha = p.alpha, beta = p.beta;
-  double* cbase = C + (long)(i0 + wr * 32 + kq) * p.ldc + j0 + wc * 64 + l15;
-  __syncthreads();
-
-  const double* a_ptr[4];
-  const double* b_ptr[4];
-#pragma unroll
-  for (int kk = 0; kk < 4; ++kk) {
-    const int sw = 4 * kk + (kq & 2);
-    a_ptr[kk] = As + kq * LDA_W + wr * 32 + (l15 ^ sw);
-    b_ptr[kk] = Bs + kq * LDB_W + wc * 64 + (l15 ^ sw);
-  }
-  double fa[2][2], fb[2][4];
-  auto load_frags = [&](int set, int buf, int kk) {
-    const double* ap = a_ptr[kk] + buf * OPER_A + kk * 4 * LDA_W;
-    const double* bp = b_ptr[kk] + buf * OPER_B + kk * 4 * LDB_W;
-    fa[set][0] = ap[0]; fa[set][1] = ap[16];
-    fb[set][0] = bp[0]; fb[set][1] = bp[16]; fb[set][2] = bp[32]; fb[set][3] = bp[48];
-  };
-  if (nchunk > 0) load_frags(0, 0, 0);
-  auto chunk_body = [&](auto Sc) {
-    constexpr int S = decltype(Sc)::value;  // LDS buffer consumed = chunk parity; register set S ^ 1 holds chunk c + 1
-#pragma unroll
-    for (int kk = 0; kk < BKW / 4; ++kk) {
-      const int cur = kk & 1;
-      if (kk + 1 < BKW / 4) load_frags(cur ^ 1, S, kk + 1);
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[cur][a], fb[cur][b], acc[a][b], 0, 0, 0);
-    }
-    store_ab(S ^ 1, S ^ 1);  // chunk c + 1 (its buffer was last read in chunk c - 1, a barrier ago)
-    load_ab(S ^ 1);          // chunk c + 3
-    __syncthreads();
-    load_frags(0, S ^ 1, 0);
-  };
-  int c = 0;
-  for (; c + 2 <= nchunk; c += 2) {
-    chunk_body(std::integral_constant<int, 0>());
-    chunk_body(std::integral_constant<int, 1>());
-  }
-  if (c < nchunk) chunk_body(std::integral_constant<int, 0>());
-  if (upper_of_diag && wc == 1) return;  // (never read, and not written either: as on the 64x64-tile kernel)
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        double* cp = cbase + (long)(16 * a + 4 * r) * p.ldc + 16 * b;
-        double v = alpha * acc[a][b][r];
-        if (beta != 0.0) v += beta * *cp;
-        *cp = v;
-      }
-}
-
 constexpr size_t LDS_ONE_PER_CU = 82432;  // > half a CU (one workgroup per CU) and <= 160 KB - the 79 KB leaf image
 
 static int tile_count(const GemmParams& p) {
@@ -894,18 +742,6 @@ hipError_t launch_gemm_f64(const GemmParams& p_in, int opA_kmajor, int opB_kmajo
   // 64x64 tiles: the whole product (few 128x128 tiles: same enumeration, tile units halve) or the `ntail` last tiles of
   // a 128x128-tile launch
   auto launch_small = [&](int ntail) -> hipError_t {
-    // throughput-bound small launches (row-major operands, uniform k, nothing special): 64x128 tiles
-    const int ntiles = ntail > 0 ? ntail : nblk;
-    if (p.wide_min > 0 && ntiles >= p.wide_min && !opA_kmajor && !opB_kmajor && p.kmode == 0 && !p.pl && p.kseg == 0 && p.kflush == 0) {
-      GemmParams q = p;
-      q.sub_base = ntail > 0 ? nblk - ntail : 0;
-      q.sub_mt = p.mt;
-      q.sub_nt = p.nt;
-      dim3 grid(2 * ntiles, 1, batch), block(256);
-      const size_t pad = p.one_per_cu ? LDS_ONE_PER_CU - sizeof(double) * 2 * (vw::OPER_A + vw::OPER_B) : 0;
-      gemm_f64_kernel_w<<<grid, block, pad, stream>>>(q);
-      return hipGetLastError();
-    }
     GemmParams q = p;
     q.mt = 2 * p.mt;
     q.nt = 2 * p.nt;
@@ -951,10 +787,7 @@ hipError_t launch_gemm_f64(const GemmParams& p_in, int opA_kmajor, int opB_kmajo
 
 hipError_t gemm_f64_enable_lds() {
   const int ldsb = (int)LDS_ONE_PER_CU;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_kernel_w), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)(LDS_ONE_PER_CU - sizeof(double) * 2 * (vw::OPER_A + vw::OPER_B)));
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_kernel_s<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_kernel_s<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_kernel_s<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);
   if (e != hipSuccess) return e;

@@ -829,10 +829,13 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
 // wait_ptr (optional): a cross-stream signal this launch has to see at wait_val or above before it ends (the driver folds
 // the panel stream's wait for the main stream's next-panel update into the leaf that precedes the first reader of those
 // columns: one polling lane at the end of a kernel that is a single workgroup anyway, instead of a runtime wait kernel of
-// 5-9 us on the chain).  The poll gives up after ~2^22 sleeps (seconds) and reports through the bad-pivot word.
+// 5-9 us on the chain).  The poll gives up after ~2^22 sleeps (seconds) and reports through the bad-pivot word -- and where that
+// word already says that an earlier poll of this evaluation gave up, it does not wait at all: the evaluation is lost, the
+// library re-runs it with event edges (api_gp.hip), and ONE limit is all the time that costs.
 __device__ __forceinline__ void poll_signal(const unsigned* ptr, unsigned val, int* info, int limit_log2) {
   long spins = 0;
   const long limit = 1L << limit_log2;
+  if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == SIGNAL_TIMEOUT_INFO) return;
   while (__hip_atomic_load(ptr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < val) {
     __builtin_amdgcn_s_sleep(4);
     if (++spins > limit) {
@@ -865,7 +868,7 @@ __global__ void signal_write_wait_kernel(unsigned* wr, const unsigned* wt, unsig
   if (threadIdx.x == 0) {
     if (wr != nullptr) __hip_atomic_store(wr, val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     if (wt != nullptr) {
-      int local = 0x7f7f7f7f;
+      int local = __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       poll_signal(wt, val, &local, poll_log2);
       if (local == SIGNAL_TIMEOUT_INFO)
         for (int p = 0; p < nb; ++p) atomicMin(info + (long)p * sinfo, SIGNAL_TIMEOUT_INFO);

@@ -60,9 +60,6 @@ struct GemmParams {
   // partial sum, C = beta C + alpha acc rounded there, and the accumulators restart -- the bits of one launch per segment in one
   // launch, with C read and written once.  Such launches run on the 64x64-tile kernel whatever their size.  0: off.
   int kflush = 0;
-  // launches (and tails of 128x128-tile launches) on the small-tile path with at least this many 128x128 tiles run on 64x128
-  // tiles when they are plain (row-major operands, uniform k, no panel list / k-segments / k-flush); 0: never
-  int wide_min = 0;
   // set by the launcher for that second launch: 64x64 tile 4 e + quadrant belongs to 128x128 tile sub_base + e of the
   // parent enumeration (sub_mt x sub_nt tiles of 128); -1: off
   int sub_base = -1, sub_mt = 0, sub_nt = 0;
@@ -102,13 +99,12 @@ constexpr int SIGNAL_TIMEOUT_INFO = -99;
 hipError_t launch_signal_write_wait(unsigned* wr, const unsigned* wt, unsigned val, int* info, hipStream_t stream, int nb = 1,
                                     int sinfo = 0, int poll_log2 = 22);
 // ---------------------------------------------------------------- thin_f64.hip
-// C[ti, tj] -= P[ti] P[tj]^T over the lower trapezoid of mt x nt tiles (tj <= ti), k in {128, 256, 512, 1024}: 16-row x 64-column
-// workgroups with direct MFMA operands, for the panel chain's short updates.  wr (optional): workgroup 0 raises *wr to val
-bool syrk_thin_supported(int k);
-// lsw (optional, k = 128): the rows of P that are the B operand (tile rows 0 .. nt - 1) in operand order, as the strip wrote them
-// lsw + lsw2 (k = 256, nt = 1): the B operand's first 128 k from lsw, the other 128 from lsw2 (two strips' copies)
-hipError_t launch_syrk_thin(const double* P, double* C, long ld, int mt, int nt, int k, hipStream_t stream, const Batch* bt = nullptr,
-                            unsigned* wr = nullptr, unsigned val = 0, const double* lsw = nullptr, const double* lsw2 = nullptr);
+// C[ti, tj] -= P[ti] P[tj]^T over the lower trapezoid of mt x nt tiles (tj <= ti), k = 128 (nt <= 2) or k = 256 (nt = 1):
+// 16-row x 64-column workgroups, for the panel chain's short updates.  wr (optional): workgroup 0 raises *wr to val
+// lsw: the rows of P that are the B operand (tile rows 0 .. nt - 1) in operand order, as the strip in front of the update wrote
+// them (launch_trsm_strip128's lsw); k = 256: the B operand's first 128 k from lsw, the other 128 from lsw2 (two strips' copies)
+hipError_t launch_syrk_thin(const double* P, double* C, long ld, int mt, int nt, int k, hipStream_t stream, const Batch* bt,
+                            unsigned* wr, unsigned val, const double* lsw, const double* lsw2 = nullptr);
 
 // ---------------------------------------------------------------- leaf_f64.hip (continued)
 // X * L^T = B in place on the m x 128 panel B (m multiple of 16, ldb even) as X = B * M^T with the leaf's inverse M.

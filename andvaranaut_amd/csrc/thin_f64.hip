@@ -1,13 +1,14 @@
 // Thin trapezoid updates of the panel chain (round 5): C[ti, tj] -= P[ti] P[tj]^T for the tile columns tj < nt of a
-// trapezoid whose k is short (128 .. 1024) and whose columns are few (1 .. 3 tile columns) -- the in-panel updates between
-// two leaves and the next super-panel's first column.  On the 64x64-tile GEMM kernel such a launch is 50-250 workgroups that
-// each walk the whole k through LDS: 8 us for k = 128, 12-16 for k = 256 over two columns, 23-33 for k = 512 over one (kernel
-// trace of N = 4096, profiles/NOTES_r05.md), nearly all of it latency -- the chain waits for every one of them.
-// Here a workgroup owns 16 rows x 64 columns (wave w: one 16x16 tile), the operands go from memory straight into MFMA
-// operand registers the way trsm_strip128 does it (lane quarter q covers k = 16 kb + 4 q + s of a 16-wide k-block: four
-// CONTIGUOUS doubles per lane and k-block for either operand), k is walked in chunks of 64 with the next chunks' loads in
-// flight, and each tile keeps four partial accumulators (one per MFMA step: a dependent fp64 MFMA issues after ~250 cycles, an
-// independent one after 64).  8 x mt x 2 nt workgroups: a whole round of the chip from 16 tile rows on.
+// trapezoid whose k is short (128, 256) and whose columns are few (1, 2 tile columns) -- the in-panel updates between two
+// leaves, the next super-panel's first column, column mode's one update per column.  On the 64x64-tile GEMM kernel such a
+// launch is 50-250 workgroups that each walk the whole k through LDS: 8 us for k = 128, 12-16 for k = 256 over two columns
+// (kernel trace of N = 4096, profiles/NOTES_r05.md), nearly all of it latency -- the chain waits for every one of them.
+// Here a workgroup owns 16 rows x 64 columns (wave w: one 16x16 tile).  Its rows come in as 1 KB row loads and reach MFMA operand
+// order through LDS; the B operand is read from the operand-order copy that the strip in front of the update wrote (lane quarter q
+// covers k = 16 kb + 4 q + s of a 16-wide k-block: 1 KB of consecutive addresses per wave load); each tile keeps four partial
+// accumulators (one per MFMA step: a dependent fp64 MFMA issues after ~250 cycles, an independent one after 64).  8 x mt x 2 nt
+// workgroups: a whole round of the chip from 16 tile rows on.  (Forms that loaded row-major operands straight into MFMA
+// registers, for k up to 1024, were bound by the texture addresser -- every quarter-wave touching 16 rows -- and are gone.)
 //
 // Optional edge of the panel stream folded into the launch (option 26 = 2; it was a one-lane launch of its own): workgroup
 // (0, 0, 0) raises *wr to val -- "everything queued on this stream before me is done".  (Round 5 also had every workgroup poll
@@ -30,12 +31,12 @@ struct ThinArgs {
   int mt, nt;
   unsigned* wr;
   unsigned val;
-  const double* lsw;  // B operand in operand order (or nullptr: from P's rows)
+  const double* lsw;  // B operand in operand order
   const double* lsw2; // K = 256: the operand-order block of the second 128 k
   long sL;
 };
 
-template <int K, int AHEAD, bool SW>
+template <int K>
 __global__ __launch_bounds__(256) void syrk_thin_kernel(ThinArgs g) {
   __builtin_amdgcn_s_setprio(3);
   // row slices -> XCDs in contiguous ranges (workgroup b runs on XCD b % 8), as the strip and the GEMM kernels map their rows
@@ -52,71 +53,54 @@ __global__ __launch_bounds__(256) void syrk_thin_kernel(ThinArgs g) {
   const int lane = tid & 63, wave = tid >> 6;
   const int n = lane & 15, q = lane >> 4;
   const long zoff = (long)blockIdx.z * g.sZ;
-  const double* arow = g.P + zoff + (long)(rs * 16 + n) * g.ld + 4 * q;
-  const double* brow = g.P + zoff + (long)(cg * 64 + wave * 16 + n) * g.ld + 4 * q;
-  // SW: 16x16 tiles of 256 doubles, tile (cb & 7, kb) of the 128-row block cb >> 3, two runs of 64 lanes x 2 doubles each
+  // B operand: 16x16 tiles of 256 doubles, tile (cb & 7, kb) of the 128-row block cb >> 3, two runs of 64 lanes x 2 doubles each
   const int cb = cg * 4 + wave;
-  const double* bsw = SW ? g.lsw + (long)blockIdx.z * g.sL + (long)(cb >> 3) * 16384 + (long)((cb & 7) * 8) * 256 + 2 * lane : nullptr;
-  const double* bsw2 = (SW && K == 256) ? g.lsw2 + (long)blockIdx.z * g.sL + (long)((cb & 7) * 8) * 256 + 2 * lane : nullptr;
+  const double* bsw = g.lsw + (long)blockIdx.z * g.sL + (long)(cb >> 3) * 16384 + (long)((cb & 7) * 8) * 256 + 2 * lane;
+  const double* bsw2 = K == 256 ? g.lsw2 + (long)blockIdx.z * g.sL + (long)((cb & 7) * 8) * 256 + 2 * lane : nullptr;
   double* out = g.C + zoff + (long)(rs * 16 + q) * g.ld + cg * 64 + wave * 16 + n;
   constexpr int NC = K / 64;
   double2_t a[NC][4][2], b[NC][4][2];
-  // SW (k = 128): the workgroup's 16 x 128 rows as four 1 KB row loads per wave, through LDS into operand order (rows 130
-  // doubles apart) -- as the strip does it
+  // the workgroup's 16 x K rows as 1 KB row loads (four rows per wave), through LDS into operand order (rows K + 2 doubles
+  // apart) -- as the strip does it
   constexpr int ALD = K + 2;  // (K = 128 or 256: a row's dword stride is 4 mod 64 either way)
-  __shared__ __attribute__((aligned(16))) double As[SW ? 16 * ALD : 2];
-  double2_t stage[SW ? K / 32 : 1];
-  if constexpr (SW) {
+  __shared__ __attribute__((aligned(16))) double As[16 * ALD];
+  double2_t stage[K / 32];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int hk = 0; hk < K / 128; ++hk)
-        stage[i * (K / 128) + hk] =
-            *reinterpret_cast<const double2_t*>(g.P + zoff + (long)(rs * 16 + 4 * wave + i) * g.ld + 128 * hk + 2 * lane);
-  }
-  auto load_chunk = [&](int c) {
+    for (int hk = 0; hk < K / 128; ++hk)
+      stage[i * (K / 128) + hk] =
+          *reinterpret_cast<const double2_t*>(g.P + zoff + (long)(rs * 16 + 4 * wave + i) * g.ld + 128 * hk + 2 * lane);
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
-      if (!SW) {
-        a[c][kb][0] = *reinterpret_cast<const double2_t*>(arow + 64 * c + 16 * kb);
-        a[c][kb][1] = *reinterpret_cast<const double2_t*>(arow + 64 * c + 16 * kb + 2);
-      }
-      if (SW) {
-        const double* src = (K == 256 && c >= 2) ? bsw2 + 256 * (4 * (c - 2) + kb) : bsw + 256 * (4 * c + kb);
-        b[c][kb][0] = *reinterpret_cast<const double2_t*>(src);
-        b[c][kb][1] = *reinterpret_cast<const double2_t*>(src + 128);
-      } else {
-        b[c][kb][0] = *reinterpret_cast<const double2_t*>(brow + 64 * c + 16 * kb);
-        b[c][kb][1] = *reinterpret_cast<const double2_t*>(brow + 64 * c + 16 * kb + 2);
-      }
+      const double* src = (K == 256 && c >= 2) ? bsw2 + 256 * (4 * (c - 2) + kb) : bsw + 256 * (4 * c + kb);
+      b[c][kb][0] = *reinterpret_cast<const double2_t*>(src);
+      b[c][kb][1] = *reinterpret_cast<const double2_t*>(src + 128);
     }
-  };
-#pragma unroll
-  for (int c = 0; c < AHEAD && c < NC; ++c) load_chunk(c);
+  }
   double cold[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) cold[r] = out[(long)(4 * r) * g.ld];
-  if constexpr (SW) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int hk = 0; hk < K / 128; ++hk)
-        *reinterpret_cast<double2_t*>(As + (4 * wave + i) * ALD + 128 * hk + 2 * lane) = stage[i * (K / 128) + hk];
-    __syncthreads();
+    for (int hk = 0; hk < K / 128; ++hk)
+      *reinterpret_cast<double2_t*>(As + (4 * wave + i) * ALD + 128 * hk + 2 * lane) = stage[i * (K / 128) + hk];
+  __syncthreads();
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
+  for (int c = 0; c < NC; ++c) {
 #pragma unroll
-      for (int kb = 0; kb < 4; ++kb) {
-        a[c][kb][0] = *reinterpret_cast<const double2_t*>(As + n * ALD + 64 * c + 16 * kb + 4 * q);
-        a[c][kb][1] = *reinterpret_cast<const double2_t*>(As + n * ALD + 64 * c + 16 * kb + 4 * q + 2);
-      }
+    for (int kb = 0; kb < 4; ++kb) {
+      a[c][kb][0] = *reinterpret_cast<const double2_t*>(As + n * ALD + 64 * c + 16 * kb + 4 * q);
+      a[c][kb][1] = *reinterpret_cast<const double2_t*>(As + n * ALD + 64 * c + 16 * kb + 4 * q + 2);
     }
   }
   const double4_t zero4 = {0.0, 0.0, 0.0, 0.0};
   double4_t p[4] = {zero4, zero4, zero4, zero4};
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
-    if (c + AHEAD < NC) load_chunk(c + AHEAD);
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
       p[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[c][kb][0].x, b[c][kb][0].x, p[0], 0, 0, 0);
@@ -129,8 +113,6 @@ __global__ __launch_bounds__(256) void syrk_thin_kernel(ThinArgs g) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) out[(long)(4 * r) * g.ld] = cold[r] - s[r];
 }
-
-bool syrk_thin_supported(int k) { return k == 128 || k == 256 || k == 512 || k == 1024; }
 
 hipError_t launch_syrk_thin(const double* P, double* C, long ld, int mt, int nt, int k, hipStream_t stream, const Batch* bt,
                             unsigned* wr, unsigned val, const double* lsw, const double* lsw2) {
@@ -146,21 +128,10 @@ hipError_t launch_syrk_thin(const double* P, double* C, long ld, int mt, int nt,
   g.lsw = lsw;
   g.lsw2 = lsw2;
   g.sL = bt ? bt->sdinv : 0;
-  if (lsw != nullptr && !(k == 128 || (k == 256 && lsw2 != nullptr && nt == 1))) return hipErrorInvalidValue;
+  if (lsw == nullptr || !((k == 128 && nt <= 2) || (k == 256 && lsw2 != nullptr && nt == 1))) return hipErrorInvalidValue;
   const dim3 grid(mt * 8, nt * 2, bt ? bt->nb : 1);
-  switch (k) {
-    case 128:
-      if (lsw) syrk_thin_kernel<128, 2, true><<<grid, 256, 0, stream>>>(g);
-      else syrk_thin_kernel<128, 2, false><<<grid, 256, 0, stream>>>(g);
-      break;
-    case 256:
-      if (lsw) syrk_thin_kernel<256, 4, true><<<grid, 256, 0, stream>>>(g);
-      else syrk_thin_kernel<256, 4, false><<<grid, 256, 0, stream>>>(g);
-      break;
-    case 512: syrk_thin_kernel<512, 4, false><<<grid, 256, 0, stream>>>(g); break;
-    case 1024: syrk_thin_kernel<1024, 4, false><<<grid, 256, 0, stream>>>(g); break;
-    default: return hipErrorInvalidValue;
-  }
+  if (k == 128) syrk_thin_kernel<128><<<grid, 256, 0, stream>>>(g);
+  else syrk_thin_kernel<256><<<grid, 256, 0, stream>>>(g);
   return hipGetLastError();
 }
 

@@ -25,6 +25,9 @@ from .optimize import find_MAP
 from .priors import HyperModel
 from .transform import _none_conrev, wgp
 
+# handles that may evaluate at once per device with in-kernel polls on their cross-stream edges (include/mi_gp.h, option 26)
+MAX_POLLING_HANDLES = 6
+
 
 
 def save_object(obj, fname):
@@ -240,6 +243,46 @@ class GPMCMC(ConsumersMixin):
 
         self.nsamp = len(self.x)
         self.train, self.test = train_test_split(np.arange(self.nsamp), train_size=training_frac)
+
+    def test_stats(self, revert=True, iwgp=False, cwgp=False, method="none", jitter=1e-6):
+        """The numeric half of ``test_plots`` (gpmcmc.py:933-976; the plots are out of scope): condition the model on the
+        training split (``train_test``; refitted there with ``method``, 'none' = the stored hypers), predict the held-out
+        points and return RMSE, mean absolute / percentage error and R^2 with the arrays ``returndat`` hands back."""
+        if getattr(self, "train", None) is None:
+            self.train_test()
+        xtrain, xtest = self.x[self.train, :], self.x[self.test, :]
+        ytrain, ytest = self.y[self.train, :], self.y[self.test, :]
+        ymtrain, ymtest = self.ym[self.train, :], self.ym[self.test, :]
+        m, gp, hypers, _ = self.__fit(xtrain, ytrain - ymtrain, method, iwgp, cwgp, jitter)
+        try:
+            xctest = np.column_stack([self.xconrevs[i].con(xtest[:, i]) for i in range(self.nx)])
+            saved = self.m, self.hypers
+            self.m, self.hypers = m, hypers
+            try:
+                mu, var = gp.predict(self._theta_from_hypers(hypers, jitter), xctest, pred_noise=True)
+            finally:
+                self.m, self.hypers = saved
+        finally:
+            gp.close()  # (self.gp was released by __fit: the next predict rebuilds it on the full data)
+        ypred, yvars = mu.reshape((-1, 1)), var.reshape((-1, 1))
+        if revert:
+            yt = ytest[:, 0]
+            ypred, yvars = self.__gh_stats(xtest, ypred, yvars, normvar=False)
+            meany = np.mean(self.y)
+        else:
+            yt = self.yconrevs[0].con(ytest[:, 0] - ymtest[:, 0])
+            meany = np.mean(self.yconrevs[0].con((self.y - self.ym)[:, 0]))
+        ypred, yvars = ypred[:, 0], yvars[:, 0]
+        out = {"rmse": float(np.sqrt(np.mean((ypred - yt) ** 2))), "mea": float(np.mean(np.abs(ypred - yt))),
+               "mpe": float(np.mean(np.abs(ypred - yt) / np.abs(yt))),
+               "r2": float(1 - np.sum((ypred - yt) ** 2) / np.sum((yt - meany) ** 2)),
+               "xtest": xtest if revert else xctest, "ytest": yt, "ypred": ypred, "yvars": yvars}
+        if self.verbose:
+            print(f"RMSE for y is: {out['rmse']:0.5e}")
+            print(f"Mean absoulte error for y is: {out['mea']:0.5e}")
+            print(f"Mean percentage error for y is: {out['mpe']:0.5%}")
+            print(f"R^2 for y is: {out['r2']:0.5f}")
+        return out
 
     def change_model(self, kernel=None, noise=None, mean=None):
         """gpmcmc.py:472-519: kernel string grammar, noise flag, mean function; scrubs the fitted model."""
@@ -497,22 +540,29 @@ class GPMCMC(ConsumersMixin):
             return max(1, min(3, nchain, base + int(0.8 * free // need)))
 
         # a lane = one host thread + one handle; the chains of a device are dealt round-robin to its lanes
-        def run_lane(dev, cs, h_existing, shared):
+        def run_lane(dev, cs, h_existing, shared, nlanes=1):
             try:
                 h = h_existing or MiGP(xin, yin, self.kernel, device=dev)
-                # Lanes that SHARE a GPU give up the look-ahead stream between 20 and 64 tile columns: the other lanes fill
-                # the idle CUs anyway and a hand-off between two streams costs ~10 us (three handles, LML + gradient: N = 6144
-                # 176 -> 202 evaluations/s, N = 8192 94 -> 97; from 72 tile columns on there is nothing in it).  The
-                # super-panel width is pinned to the one the two-stream driver would pick, so the arithmetic -- and every
-                # draw -- is bit-identical to the default schedule.
+                # Lanes that SHARE a GPU give up the look-ahead stream up to 64 tile columns (two streams start at 8 since
+                # column mode): the other lanes fill the idle CUs anyway and a hand-off between two streams costs ~5-10 us
+                # (three handles, LML + gradient: N = 6144 176 -> 202 evaluations/s, N = 8192 94 -> 97; from 72 tile columns on
+                # there is nothing in it).  The super-panel width is pinned to the one the two-stream driver would pick, so
+                # the arithmetic -- and every draw -- is bit-identical to the default schedule.
                 ntc = (len(yin) + 127) // 128
-                pinned = shared and 20 <= ntc <= 64
+                pinned = shared and 8 <= ntc <= 64
+                before26 = None
+                if shared and not pinned and nlanes > MAX_POLLING_HANDLES:
+                    # Two-stream lanes enqueue in-kernel polls ahead of the writes they wait for (include/mi_gp.h, option 26):
+                    # tested with six handles evaluating at once per device.  Beyond that the lanes use event edges from the
+                    # start (same bits) instead of finding out through a poll limit.
+                    before26 = h.get_option(26, 2)
+                    h.set_option(26, 0)
                 if pinned:
                     # the caller's own handle gets its previous settings back afterwards (library defaults: look-ahead by
                     # size = 1, super-panel width by size = 0)
                     before = (h.get_option(2, 0), h.get_option(0, 1))
-                    if ntc <= 60:  # (api_gp.hip NARROW_PANELS_MAX_TILES: above it both schedules use 8-tile super-panels)
-                        h.set_option(2, 4)
+                    if 20 <= ntc <= 60:  # (api_gp.hip NARROW_PANELS_MAX_TILES: above it both schedules use 8-tile super-panels;
+                        h.set_option(2, 4)  # up to 24 tile columns the whole problem runs in column mode: no panels at all)
                     h.set_option(0, 0)
                 try:
                     lik = self._warp_likelihood(h, x, y, xin, iwgp, cwgp) if (iwgp or cwgp) else None
@@ -524,9 +574,12 @@ class GPMCMC(ConsumersMixin):
                 finally:
                     if h_existing is None:
                         h.close()
-                    elif pinned:
-                        h.set_option(2, before[0])
-                        h.set_option(0, before[1])
+                    else:
+                        if pinned:
+                            h.set_option(2, before[0])
+                            h.set_option(0, before[1])
+                        if before26 is not None:
+                            h.set_option(26, before26)
             except Exception as e:  # noqa: BLE001 - reported by the caller's thread
                 errors.append(e)
 
@@ -577,7 +630,7 @@ class GPMCMC(ConsumersMixin):
             for lane in range(k):
                 mine = cs[lane::k]
                 if mine:
-                    threads.append(threading.Thread(target=run_lane, args=(dev, mine, gp if (dev == self.device and lane == 0) else None, k > 1)))
+                    threads.append(threading.Thread(target=run_lane, args=(dev, mine, gp if (dev == self.device and lane == 0) else None, k > 1, k)))
         for t in threads:
             t.start()
         for t in threads:

@@ -29,6 +29,9 @@ enum { MI_GP_RBF = 0, MI_GP_MATERN52 = 1, MI_GP_MATERN32 = 2, MI_GP_EXPONENTIAL 
 enum { MI_GP_OP_ADD = 0, MI_GP_OP_MUL = 1 };
 #define MI_GP_MAX_KERN 8
 
+/* libmi_gp.so is built with -fvisibility=hidden: these entry points are the only symbols it exports */
+#define MI_GP_API __attribute__((visibility("default")))
+
 typedef struct mi_gp_handle mi_gp_handle;
 
 /* kernel string of GPMCMC.change_model (gpmcmc.py:497-515) already split into ids and ops */
@@ -53,27 +56,27 @@ typedef struct mi_gp_buffers {
   double* W_dev;       /* np x lda  K^-1 (lower triangle) and GEMM scratch (same entry points; else may be NULL) */
 } mi_gp_buffers;
 
-const char* mi_gp_last_global_error(void);
-const char* mi_gp_last_error(mi_gp_handle* h);
+MI_GP_API const char* mi_gp_last_global_error(void);
+MI_GP_API const char* mi_gp_last_error(mi_gp_handle* h);
 
-int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out);
-int mi_gp_destroy(mi_gp_handle* h);
-long mi_gp_padded_n(const mi_gp_handle* h);   /* n rounded up to a multiple of 128 */
-int mi_gp_num_theta(const mi_gp_handle* h);   /* nkern*d + 2*nkern + 2 */
-void* mi_gp_stream(const mi_gp_handle* h);    /* the handle's hipStream_t */
-int mi_gp_set_data(mi_gp_handle* h, const mi_gp_buffers* buffers);
+MI_GP_API int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out);
+MI_GP_API int mi_gp_destroy(mi_gp_handle* h);
+MI_GP_API long mi_gp_padded_n(const mi_gp_handle* h);   /* n rounded up to a multiple of 128 */
+MI_GP_API int mi_gp_num_theta(const mi_gp_handle* h);   /* nkern*d + 2*nkern + 2 */
+MI_GP_API void* mi_gp_stream(const mi_gp_handle* h);    /* the handle's hipStream_t */
+MI_GP_API int mi_gp_set_data(mi_gp_handle* h, const mi_gp_buffers* buffers);
 
 /* LML(theta) = -1/2 |L^-1 y|^2 - sum log L_ii - n/2 log 2pi with L = chol(K(theta) + gv I + jitter I).
  * Replaces the logp evaluation of gp.marginal_likelihood (gpmcmc.py:321-323; explicit form :311-318). */
-int mi_gp_lml(mi_gp_handle* h, const double* theta_host, double* lml_out);
+MI_GP_API int mi_gp_lml(mi_gp_handle* h, const double* theta_host, double* lml_out);
 /* sum log L_ii and |L^-1 y|^2 of the last factorisation */
-int mi_gp_lml_parts(mi_gp_handle* h, double* logdet_out, double* quad_out);
+MI_GP_API int mi_gp_lml_parts(mi_gp_handle* h, double* logdet_out, double* quad_out);
 
 /* LML and its gradient w.r.t. the natural parameters, grad_out[mi_gp_num_theta()] in theta order
  * (d/d jitter equals d/d gv):  dLML/dtheta_k = 1/2 tr((alpha alpha^T - K^-1) dK/dtheta_k), K^-1 = L^-T L^-1
  * formed on the fp64 MFMA GEMM.  Replaces the dlogp half of model.logp_dlogp_function that
  * pm.find_MAP (gpmcmc.py:332,345,357) and pm.sample / NUTS (gpmcmc.py:351) call per step. */
-int mi_gp_lml_grad(mi_gp_handle* h, const double* theta_host, double* lml_out, double* grad_out);
+MI_GP_API int mi_gp_lml_grad(mi_gp_handle* h, const double* theta_host, double* lml_out, double* grad_out);
 
 /* Batched evaluation: `count` covariances of the SAME inputs, one theta each, factorised in lockstep (every kernel launch
  * of the evaluation carries blockIdx.z = problem).  One evaluation below N ~ 10^4 is bound by its serial panel chain and
@@ -91,9 +94,9 @@ typedef struct mi_gp_batch_buffers {
   long stride_zw;
   int count;
 } mi_gp_batch_buffers;
-int mi_gp_set_batch(mi_gp_handle* h, const mi_gp_batch_buffers* buffers);
-int mi_gp_lml_batch(mi_gp_handle* h, int k, const double* thetas_host, double* lml_out, int* info_out);
-int mi_gp_lml_grad_batch(mi_gp_handle* h, int k, const double* thetas_host, double* lml_out, double* grads_out, int* info_out);
+MI_GP_API int mi_gp_set_batch(mi_gp_handle* h, const mi_gp_batch_buffers* buffers);
+MI_GP_API int mi_gp_lml_batch(mi_gp_handle* h, int k, const double* thetas_host, double* lml_out, int* info_out);
+MI_GP_API int mi_gp_lml_grad_batch(mi_gp_handle* h, int k, const double* thetas_host, double* lml_out, double* grads_out, int* info_out);
 
 /* Data-side gradients at the theta of the last successful mi_gp_lml_grad (K^-1 and alpha still resident):
  *   mi_gp_alpha  : alpha = K^-1 y (n doubles to the host); dLML/dy = -alpha
@@ -102,34 +105,34 @@ int mi_gp_lml_grad_batch(mi_gp_handle* h, int k, const double* thetas_host, doub
  * with the hyper-parameters (cwgp / iwgp, gpmcmc.py:211-279, Jacobian term :319) and through the free
  * observation rows of inverse_opt (gpmcmc.py:1096-1101,1156-1165); PyMC obtains both by autodiff.  Any d (beyond 128 input
  * dimensions mi_gp_grad_x runs one pass per window of 128 output dimensions). */
-int mi_gp_alpha(mi_gp_handle* h, double* alpha_host);
-int mi_gp_grad_x(mi_gp_handle* h, double* gx_dev);
+MI_GP_API int mi_gp_alpha(mi_gp_handle* h, double* alpha_host);
+MI_GP_API int mi_gp_grad_x(mi_gp_handle* h, double* gx_dev);
 /* Optional per-point diagonal (n doubles, device, borrowed; NULL removes it) added to K on top of theta's
  * (gv, jitter): the noise vector `ynoise` of inverse_opt (gpmcmc.py:1134-1158, K += diag(ynoise)). */
-int mi_gp_set_diag(mi_gp_handle* h, const double* diag_dev);
+MI_GP_API int mi_gp_set_diag(mi_gp_handle* h, const double* diag_dev);
 
 /* Factorise K(theta) + jitter I + gv I (the conditional's form, [3P] Marginal._build_conditional) and
  * keep L and beta = L^-1 y on the device for mi_gp_predict.  Replaces the first half of
  * gp.predict(x, point=hyps, diag=True, pred_noise=True) at gpmcmc.py:593-594. */
-int mi_gp_factor(mi_gp_handle* h, const double* theta_host);
+MI_GP_API int mi_gp_factor(mi_gp_handle* h, const double* theta_host);
 /* Posterior mean and diagonal variance at m new points (Xnew_dev m x d, converted inputs):
  * A = L^-1 K(X, X*), mu = A^T beta, var = kdiag - colsum(A o A) (+ gv if pred_noise); the same algebra
  * is written out in-tree at gpmcmc.py:766-778.  work_dev is caller scratch of
  * ceil(m/128)*128 rows x ldw (ldw even, >= mi_gp_padded_n()); mean_dev / var_dev receive m doubles. */
-int mi_gp_predict(mi_gp_handle* h, const double* Xnew_dev, int m, double* work_dev, long ldw, double* mean_dev,
+MI_GP_API int mi_gp_predict(mi_gp_handle* h, const double* Xnew_dev, int m, double* work_dev, long ldw, double* mean_dev,
                   double* var_dev, int pred_noise);
 /* The same conditional through U = L^-T (formed once per mi_gp_factor, N^3/3 flops): A = K(X*, X) U is one GEMM with
  * a triangular k-range instead of the blocked triangular solve -- the path for sweeps of many points at fixed
  * hyper-parameters (BO's 10 000-point proposals at gpmcmc.py:691-697).  Needs Z_dev / W_dev; work_dev must hold
  * 2 * ceil(m/128)*128 rows x ldw. */
-int mi_gp_predict_u(mi_gp_handle* h, const double* Xnew_dev, int m, double* work_dev, long ldw, double* mean_dev,
+MI_GP_API int mi_gp_predict_u(mi_gp_handle* h, const double* Xnew_dev, int m, double* work_dev, long ldw, double* mean_dev,
                     double* var_dev, int pred_noise);
 /* The same plus d mu / d x* and d var / d x* (m x d each, device): d mu = sum_i alpha_i dk(x_i,x*)/dx*,
  * d var = -2 sum_i w_i dk(x_i,x*)/dx* with w = K^-1 k(X,x*).  Replaces the PyTensor graph of the single-point
  * predictive that BO's refinement differentiates (gpmcmc.py:766-801).  Needs Z_dev / W_dev; work_dev must hold
  * 2 * ceil(m/128)*128 rows x ldw (the upper half receives the w rows); (nkern + 1) * d doubles must fit 60 KB of LDS
  * (d <= 1536 with four components, 3840 with one). */
-int mi_gp_predict_grad(mi_gp_handle* h, const double* Xnew_dev, int m, double* work_dev, long ldw, double* mean_dev,
+MI_GP_API int mi_gp_predict_grad(mi_gp_handle* h, const double* Xnew_dev, int m, double* work_dev, long ldw, double* mean_dev,
                        double* var_dev, int pred_noise, double* dmean_dev, double* dvar_dev);
 
 /* tuning knobs (benchmarks / A-B tests), ALL per handle -- nothing here is process-wide:
@@ -157,31 +160,32 @@ int mi_gp_predict_grad(mi_gp_handle* h, const double* Xnew_dev, int m, double* w
  *      instead of 11-12 on MI355X; N = 6144 3.40 -> 3.26 ms); 2 (default) the same protocol with the PANEL stream's halves
  *      folded into launches of the library: its write + wait at a super-panel boundary is one one-lane launch, its wait
  *      for the next-panel update is a poll at the end of the leaf in front of the first reader (N = 4096 1.995 -> 1.965 ms).
- *      A poll that sees nothing for seconds gives up and the evaluation (a batch: the whole batch) returns -2 with
- *      "a cross-stream signal ... was not seen within its poll limit"; the handle stays usable.  Modes 1 and 2 need
- *      hipDeviceAttributeCanUseStreamWaitValue: mi_gp_create queries it and falls back to 0 (the option then stays 0
- *      whatever is set).  The panel stream's polls are enqueued ahead of the main-stream writes they wait for, which is
- *      safe while the two streams of a handle do not queue behind each other in one hardware queue: keep at most six
- *      handles evaluating concurrently per device with mode 2 (tests run six), or use mode 0 / 1 beyond that.
+ *      Modes 1 and 2 need hipDeviceAttributeCanUseStreamWaitValue: mi_gp_create queries it and falls back to 0 (the
+ *      option then stays 0 whatever is set).  The panel stream's polls are enqueued AHEAD of the main-stream writes they
+ *      wait for, which needs the two streams' kernels to be dispatched concurrently.  Where they are not -- rocprofv3
+ *      --pmc, AMD_SERIALIZE_KERNEL / HIP_LAUNCH_BLOCKING, more handles evaluating at once than the device has hardware
+ *      queues for (six per device are tested) -- such a poll ends only through its limit.  The library deals with that
+ *      itself (the reference's evaluations never fail for reasons of scheduling, gpmcmc.py:331-339): mi_gp_create probes
+ *      the dispatch once (a one-lane poll with a limit of a few ms) and starts with mode 0 where it is serialised; and an
+ *      evaluation whose poll gives up (every later poll of it then returns at once) makes the handle switch to mode 0 for
+ *      good and is evaluated AGAIN before the call returns -- the caller sees the result, mi_gp_last_error names the
+ *      demotion once, mi_gp_get_option(40) reads 1.  Setting option 26 to 1 or 2 again re-arms the polls.  Only a second
+ *      time-out in the same call returns -2 ("a cross-stream signal ... was not seen within its poll limit"); the handle
+ *      stays usable.  Same bits in every mode.
  *   27 log2 of the number of sleeps after which such a poll gives up (default 22 = seconds; 4 .. 30)
- *   28 test hook: the next two-stream evaluation leaves one main-stream signal unwritten (its poll must give up)
- *   29 the main stream's update of the next super-panel's columns 2.. runs one workgroup per CU: 0 never, 1 always, -1 (default)
- *      for problems of up to 48 tile columns (N = 4096 1.640 -> 1.629 ms, 6144 2.833 -> 2.806; N >= 8192 loses 1.5-2 %); scheduling only
+ *   28 test hook: the next two-stream evaluation leaves one main-stream signal unwritten (its poll must give up); needs
+ *      option 26 = 2 (refused otherwise: a runtime wait has no limit) and is cleared by the next evaluation whatever its schedule
  *   30 gradient evaluations of 64 tile columns and more: the leaf blocks and the block-doubling levels of U = L^-T with nodes of
  *      up to this many tiles start on the main stream inside the factorisation's chain-bound last steps instead of behind it
  *      (default 16, 0: never; same launches per tile, bit-identical gradients; N = 16384 LML + gradient 69.8 -> 69.4 ms)
  *   31 ... in the steps with at most this many trailing tile columns, half as many new columns per step (default 48)
- *   32 in-panel updates (between two leaves of a super-panel) of at most this many 16-row x 128-column slices run on the thin
- *      direct-operand kernel (default 2048; 0: never); 33: ... and of at most this many tile columns (default 2); 34: ... and
- *      with k up to this (default 128; 128 / 256 / 512 / 1024 are implemented).  Regroups sums (agreement to rounding); the
+ *   32 in-panel updates (between two leaves of a super-panel) with k = 128 over at most two tile columns and at most this many
+ *      16-row x 128-column slices run on the thin kernel (default 2048; 0: never).  Regroups sums (agreement to rounding); the
  *      choice depends on the update's shape alone, so every schedule and a batch return the same bits.
  *   35 extended super-panels: a super-panel with at most this many tile rows below it (default 32; 0: never) also applies its
  *      in-panel updates to the NEXT super-panel's first tile column, level by level, instead of one update of that column
  *      behind the panel (problems of 20 tile columns or more, not the last 8 columns).  Regroups that column's sums; a rule of
  *      the shape alone as well.
- *   36 the main stream's update of the next super-panel's other columns in one launch per recursion level of that panel, each with
- *      its own signal, in steps with at most this many trailing tile columns (default 0 = never: measured slower, N = 4096 1.456 ->
- *      1.509 ms -- the main stream's launches and signals add up to more than the chain saves); scheduling only
  *   37 column mode: the last this-many tile columns (default 24; 0: never) are factored column by column -- leaf, strip and one
  *      k = 256 thin update of the next column on the panel stream; older columns reach a column through k = 128 updates on the
  *      main stream, a column behind the chain.  Problems of up to that many tile columns run in it from the start, on two
@@ -190,22 +194,24 @@ int mi_gp_predict_grad(mi_gp_handle* h, const double* Xnew_dev, int m, double* w
  *   38 column mode of a BATCH: the main stream applies its k = 128 updates to the columns behind the chain's next one in
  *      k-segmented launches of this many columns (default 8; 1: one launch per column as for a single evaluation).  The tile
  *      takes every 128-column partial sum as a launch of its own would round it: same bits, scheduling only.
- *   39 GEMM launches on the small-tile path (and tails of 128x128-tile launches) of at least this many 128x128 tiles run on the
- *      64x128-tile kernel (plain launches only: row-major operands, uniform k); default 0 = never: as built it is slower than
- *      the 64x64-tile kernel (N = 8192 4.85 -> 5.25 ms at 256, 5.56 at 64).  Same bits.
- * 8, 14, 16, 18, 19, 21, 24, 26, 27, 29, 30, 31, 36, 38 and 39 only change scheduling (bit-identical results); 20 moves tiles between the two GEMM kernels (same k order); 2, 4-7, 9, 32-35 and 37 regroup sums (agreement to rounding), and so does 0 where
- * it changes the super-panel width (20 to 60 tile columns).
+ * 8, 14, 16, 18, 19, 21, 24, 26, 27, 30, 31 and 38 only change scheduling (bit-identical results); 20 moves tiles between the
+ * two GEMM kernels (same k order); 2, 4-7, 9, 32, 35 and 37 regroup sums (agreement to rounding), and so does 0 where it changes
+ * the super-panel width (20 to 60 tile columns).
  * Unknown ids return -1.  (Round 1's options 1, 3, 10-13 -- GEMM variants, hipGraph replay, persistent bulk kernels,
- * exclusive leaf, fused leaf + strip -- are gone with the code they selected.) */
-int mi_gp_set_option(mi_gp_handle* h, int what, int value);
+ * exclusive leaf, fused leaf + strip -- and round 5's 29, 33, 34, 36, 39 -- forms that lost their A/B: the next-panel update's
+ * occupancy as a knob, strided thin updates, that update in pieces, 64x128 tiles -- are gone with the code they selected.) */
+MI_GP_API int mi_gp_set_option(mi_gp_handle* h, int what, int value);
+/* current value of a knob, the library's own defaults included; 40 (read-only): 1 once the handle has switched its cross-stream
+ * edges to events by itself (option 26) */
+MI_GP_API int mi_gp_get_option(mi_gp_handle* h, int what, int* value);
 
 /* profiling: level 0 none, 1 per-phase HIP events, 2 additionally per-GEMM-launch HIP events */
-int mi_gp_set_profiling(mi_gp_handle* h, int level);
+MI_GP_API int mi_gp_set_profiling(mi_gp_handle* h, int level);
 /* out[0..12] = assemble_ms, cholesky_ms, reduce_ms, total_ms, gemm_ms (sum over launches),
  *             gemm_flops (algorithmic), number of gemm launches, trtri_ms, lauum_ms, contract_ms,
  *             then the same three GEMM figures for the 128x128-tile kernel (gemm_f64_kernel_b) alone
  *             -- of the last evaluation (profiling level >= 1) */
-int mi_gp_timers(mi_gp_handle* h, double* out, int n);
+MI_GP_API int mi_gp_timers(mi_gp_handle* h, double* out, int n);
 
 /* ---- block-level operations (also used by the multi-GPU driver and the parity tests) ---- */
 
@@ -216,14 +222,14 @@ int mi_gp_timers(mi_gp_handle* h, double* out, int n);
  * operands (0 full, 1 k>=col-tile start, 2 k<row-tile end, 3 k>=row-tile start, 4 k<col-tile end).
  * Replaces the OpenBLAS dgemm/dsyrk calls inside LAPACK dpotrf/dtrtri/dlauum that PyTensor's
  * Cholesky Op reaches (gpmcmc.py:313; scipy.linalg.cholesky). */
-int mi_gp_gemm_f64(int transa, int transb, int m, int n, int k, double alpha, const double* A_dev, long lda,
+MI_GP_API int mi_gp_gemm_f64(int transa, int transb, int m, int n, int k, double alpha, const double* A_dev, long lda,
                    const double* B_dev, long ldb, double beta, double* C_dev, long ldc, int tri, int kmode,
                    int batch, long strideA, long strideB, long strideC, void* hip_stream);
 
 /* The same product (batch 1) with the launcher's knobs per call: launches with fewer than small_below 128x128 tiles run on
  * 64x64 tiles (handle option 7), tail_small (option 9), band height of the trapezoid tile order (option 14), one workgroup
  * per CU (option 8's effect).  For A/B measurements of single launches and the GEMM tests. */
-int mi_gp_gemm_f64_tuned(int transa, int transb, int m, int n, int k, double alpha, const double* A_dev, long lda,
+MI_GP_API int mi_gp_gemm_f64_tuned(int transa, int transb, int m, int n, int k, double alpha, const double* A_dev, long lda,
                          const double* B_dev, long ldb, double beta, double* C_dev, long ldc, int tri, int kmode,
                          int small_below, int tail_small, int band, int one_per_cu, void* hip_stream);
 
@@ -231,7 +237,7 @@ int mi_gp_gemm_f64_tuned(int transa, int transb, int m, int n, int k, double alp
  * 128) of A at A_dev + g * kseg_stride with rows lda apart, the same for B.  This is how the GEMM kernels read the sharded
  * driver's piece-major panel buffers (one contiguous piece per tile column, sent as soon as it is final).  small_below < 0:
  * the launcher's default. */
-int mi_gp_gemm_nt_kseg(int m, int n, int k, double alpha, const double* A_dev, long lda, const double* B_dev, long ldb,
+MI_GP_API int mi_gp_gemm_nt_kseg(int m, int n, int k, double alpha, const double* A_dev, long lda, const double* B_dev, long ldb,
                        int kseg, long kseg_stride, double beta, double* C_dev, long ldc, int tri, int small_below,
                        void* hip_stream);
 
@@ -239,7 +245,7 @@ int mi_gp_gemm_nt_kseg(int m, int n, int k, double alpha, const double* A_dev, l
  * col0.. of the global matrix; noise + jitter go on the global diagonal, identity in the padding
  * (rows >= nrows / columns >= ncols of the padded block).  Same kernel as the single-GPU assembly
  * (gpmcmc.py:282-312). */
-int mi_gp_assemble_block(int d, int nkern, const int* kernel_ids, const int* ops, const double* theta_dev,
+MI_GP_API int mi_gp_assemble_block(int d, int nkern, const int* kernel_ids, const int* ops, const double* theta_dev,
                          const double* Xrows_dev, int nrows, const double* Xcols_dev, int ncols, int row0, int col0,
                          double* K_dev, long ldk, int rows_pad, int cols_pad, int noise_form, void* hip_stream);
 
@@ -248,11 +254,11 @@ int mi_gp_assemble_block(int d, int nkern, const int* kernel_ids, const int* ops
  * the explicit 128x128 inverses of the panel's diagonal blocks (lower triangular, in an internal tile order; the strip solves are
  * products with them, and mi_gp_trsm_block reuses them); *info_dev receives atomicMin(col_base + bad pivot index + 1).
  * LAPACK dpotrf panel step. */
-int mi_gp_chol_panel(double* A_dev, long lda, int row_tiles, int w_tiles, double* dinv_dev, int* info_dev,
+MI_GP_API int mi_gp_chol_panel(double* A_dev, long lda, int row_tiles, int w_tiles, double* dinv_dev, int* info_dev,
                      int col_base, void* hip_stream);
 
 /* out_dev[1] = sum_i log L[i][i], out_dev[2] = sum_i beta[i]^2 over n entries (one workgroup). */
-int mi_gp_lml_partial(const double* L_dev, long ld, const double* beta_dev, int n, double* out_dev, void* hip_stream);
+MI_GP_API int mi_gp_lml_partial(const double* L_dev, long ld, const double* beta_dev, int n, double* out_dev, void* hip_stream);
 
 /* ---- sharded gradient ("gradient at C4 scale needs distributed K^-1"): the reference gets dLML/dtheta from
  * pytensor.grad through Cholesky.L_op behind pm.find_MAP / pm.sample (gpmcmc.py:345,351); the sharded driver
@@ -262,17 +268,17 @@ int mi_gp_lml_partial(const double* L_dev, long ld, const double* beta_dev, int 
  * L_dev (element (0,0) first, leading dimension ldl); dinv_dev: the 16384-double leaf inverses mi_gp_chol_panel wrote,
  * indexed by global tile; B_dev points at the first of those columns of the m-row right-hand side (m multiple of 128).
  * With B = rows J of the identity this yields rows J of U = L^-T.  LAPACK dtrsm('R','L','T','N'). */
-int mi_gp_trsm_block(const double* L_dev, long ldl, const double* dinv_dev, int c0_tiles, int w_tiles, double* B_dev,
+MI_GP_API int mi_gp_trsm_block(const double* L_dev, long ldl, const double* dinv_dev, int c0_tiles, int w_tiles, double* B_dev,
                      long ldb, int m, void* hip_stream);
 
 /* out = U x for an upper-triangular n x n U (alpha = L^-T beta, gpmcmc.py:315). */
-int mi_gp_trmv_upper(const double* U_dev, long ld, const double* x_dev, int n, double* out_dev, void* hip_stream);
+MI_GP_API int mi_gp_trmv_upper(const double* U_dev, long ld, const double* x_dev, int n, double* out_dev, void* hip_stream);
 
 /* grad_dev[ntheta] = 1/2 sum (alpha_i alpha_j - Kinv_ij) dK_ij/dtheta over the column slab [col0, col0 + cols) of the
  * lower triangle (rows >= col0; diagonal counted once).  W_dev points at element (row0, col0) of K^-1 (row0 <= col0,
  * all multiples of 64); part_dev: mi_gp_grad_contract_block_scratch() doubles.  Slab sums add up to mi_gp_lml_grad's. */
-long mi_gp_grad_contract_block_scratch(int n, int col0, int cols, int ntheta);
-int mi_gp_grad_contract_block(int d, int nkern, const int* kernel_ids, const int* ops, const double* theta_dev,
+MI_GP_API long mi_gp_grad_contract_block_scratch(int n, int col0, int cols, int ntheta);
+MI_GP_API int mi_gp_grad_contract_block(int d, int nkern, const int* kernel_ids, const int* ops, const double* theta_dev,
                               const double* X_dev, int n, const double* W_dev, long ldw, int row0, int col0, int cols,
                               const double* alpha_dev, double* part_dev, long part_len, double* grad_dev,
                               void* hip_stream);
@@ -314,13 +320,13 @@ typedef struct {
   int* info_dev;           /* [1] bad-pivot word: reset by begin, atomicMin(global column + 1) */
   double* out_dev;         /* [4] scalars of finish */
 } mi_gp_shard_config;
-int mi_gp_shard_create(const mi_gp_shard_config* cfg, mi_gp_shard** out);
-int mi_gp_shard_destroy(mi_gp_shard* s);
-int mi_gp_shard_begin(mi_gp_shard* s, int noise_form, void* main_stream, void* side_stream);
-int mi_gp_shard_step(mi_gp_shard* s, int j, void* main_stream, void* side_stream);
-int mi_gp_shard_finish(mi_gp_shard* s, void* main_stream, void* side_stream);
+MI_GP_API int mi_gp_shard_create(const mi_gp_shard_config* cfg, mi_gp_shard** out);
+MI_GP_API int mi_gp_shard_destroy(mi_gp_shard* s);
+MI_GP_API int mi_gp_shard_begin(mi_gp_shard* s, int noise_form, void* main_stream, void* side_stream);
+MI_GP_API int mi_gp_shard_step(mi_gp_shard* s, int j, void* main_stream, void* side_stream);
+MI_GP_API int mi_gp_shard_finish(mi_gp_shard* s, void* main_stream, void* side_stream);
 /* `stream` waits until tile column c of the panel this rank factored last (begin: panel 0; step j: panel j + 1) is staged */
-int mi_gp_shard_wait_piece(mi_gp_shard* s, int c, void* hip_stream);
+MI_GP_API int mi_gp_shard_wait_piece(mi_gp_shard* s, int c, void* hip_stream);
 /* options: 0 bulk updates at one workgroup per CU while this rank's side stream factors the next panel (default 1);
  *          1 record per-step HIP events (update / factor / stage on the side stream, bulk on the main stream);
  *          2 update the panel this rank factors in the NEXT step first and alone, so that its chain does not wait for the
@@ -338,17 +344,17 @@ int mi_gp_shard_wait_piece(mi_gp_shard* s, int c, void* hip_stream);
  * Options 2 and 3 and the world size change which launches update a panel (the early next-panel update goes through the
  * ordinary launcher and may run on 64x64 tiles where the panel-list launch uses 128x128), i.e. they regroup sums: results
  * then agree to rounding (1e-11 relative on the LML in the tests), not bit for bit. */
-int mi_gp_shard_set_option(mi_gp_shard* s, int what, int value);
+MI_GP_API int mi_gp_shard_set_option(mi_gp_shard* s, int what, int value);
 /* per-step phase times of the last evaluation (option 1; call after synchronising): out[4 * j + 0..3] =
  * update_ms, factor_ms, stage_ms, bulk_ms of step j (0 where the step had no such phase; factor of panel 0 is in
  * out[4 * npanels + 1], its staging in out[4 * npanels + 2]); returns the number of steps written, < 0 on error */
-int mi_gp_shard_times(mi_gp_shard* s, double* out, int max_steps);
+MI_GP_API int mi_gp_shard_times(mi_gp_shard* s, double* out, int max_steps);
 /* out[j * panel_tiles + c] = ms from the start of step j's chain to the end of the staging of tile column c of the panel it
  * produces (row npanels: panel 0, from the start of its factorisation); option 1; returns the number of steps written */
-int mi_gp_shard_piece_times(mi_gp_shard* s, double* out, int max_steps);
+MI_GP_API int mi_gp_shard_piece_times(mi_gp_shard* s, double* out, int max_steps);
 /* 0: the chain runs on side_stream (it must then wait for panel j as well), 1: on main_stream (option 3) */
-int mi_gp_shard_chain_stream(const mi_gp_shard* s);
-const char* mi_gp_shard_last_error(mi_gp_shard* s);
+MI_GP_API int mi_gp_shard_chain_stream(const mi_gp_shard* s);
+MI_GP_API const char* mi_gp_shard_last_error(mi_gp_shard* s);
 
 #ifdef __cplusplus
 }

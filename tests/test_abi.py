@@ -22,6 +22,27 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.EXPORTS) == names, "andvaranaut_amd/_lib.py:EXPORTS is out of sync with include/mi_gp.h"
 
 
+def test_library_exports_nothing_but_the_c_abi():
+    """VERDICT r5: the C-ABI is the boundary -- no internal launcher (migp::launch_gemm_f64, chol_panel_blocks, ...), kernel
+    handle object or C++ runtime template instantiation is linkable from outside (-fvisibility=hidden + csrc/libmi_gp.map)."""
+    import shutil
+    import subprocess
+
+    import pytest
+
+    from andvaranaut_amd import _lib
+
+    nm = shutil.which("nm") or shutil.which("llvm-nm", path="/opt/rocm/lib/llvm/bin")
+    if nm is None:
+        pytest.skip("no nm")
+    out = subprocess.check_output([nm, "-D", "--defined-only", _lib.LIB_PATH], text=True)
+    syms = [line.split() for line in out.splitlines() if line.strip()]
+    assert len(syms) >= 10
+    names = sorted(s[-1] for s in syms)
+    assert names == _declared(), sorted(set(names) ^ set(_declared()))
+    assert all(s[-2] == "T" for s in syms), [s for s in syms if s[-2] != "T"]
+
+
 def test_bad_arguments_are_reported_not_crashed():
     import ctypes
 

@@ -53,6 +53,30 @@ def test_config1_map_fit_matches_oracle_backed_map_and_predicts():
     assert np.allclose(yc[:, 0], mu_o, rtol=1e-6, atol=1e-8) and np.allclose(yvc[:, 0], var_o, rtol=1e-5, atol=1e-10)
 
 
+def test_holdout_rmse_drawn_the_way_the_tutorial_draws_its_test_points():
+    """SURVEY 8c(6) / tutorial.ipynb cells 22-30: 100 Latin-hypercube samples, maxmin / meanstd conversions, fit(restarts=1) on all
+    of them, train_test(0.9), then test_plots' numbers -- the stored hypers conditioned on the 90 training points, the 10 held-out
+    samples predicted and reverted.  The notebook records RMSE 1.44e-4, R^2 1.00000 on its own unseeded sample and split; the
+    contract's bar is <~ 2e-4.  (The test above draws its test points uniformly over the box instead -- corners included, which
+    are extrapolation for the normal-prior input -- and measures 2.7e-4.)"""
+    from andvaranaut_amd import maxmin, meanstd
+
+    rmses, r2s = [], []
+    for seed in (1, 2, 3):
+        g, _ = _tutorial_gp(n=100, seed=seed)
+        g.change_conrevs([maxmin(g.x[:, 0]), maxmin(g.x[:, 1])], [meanstd(g.y[:, 0])])
+        g.fit(restarts=1)
+        for split in range(4):
+            np.random.seed(100 * seed + split)  # (train_test_split draws from numpy's global generator, as in the reference)
+            g.train_test(training_frac=0.9)
+            assert len(g.train) == 90 and len(g.test) == 10
+            st_ = g.test_stats(revert=True)
+            rmses.append(st_["rmse"])
+            r2s.append(st_["r2"])
+    print("holdout RMSE per (sample, split):", ["%.2e" % r for r in rmses])
+    assert np.median(rmses) <= 2e-4 and min(r2s) > 0.9999, (rmses, r2s)
+
+
 def test_matern_noise_fit_train_test_and_change_model():
     g, fun = _tutorial_gp(kernel="Matern52", noise=True, n=90, seed=2)
     g.fit(method="map")
@@ -80,6 +104,30 @@ def test_chains_sharing_a_gpu_run_concurrently_with_identical_draws():
     for name in ("l", "kv", "gv"):
         assert np.array_equal(out[1].posterior[name], out[3].posterior[name]), name
     assert np.array_equal(out[1].sample_stats["lp"], out[3].sample_stats["lp"])
+
+
+@pytest.mark.parametrize("n,draws", [(1100, 12), (8320, 4)])
+def test_eight_lanes_on_one_device_stay_inside_the_documented_limit(n, draws):
+    """ADVICE r5 / VERDICT r5 item 3: include/mi_gp.h allows six handles with in-kernel polls per device.  chains_per_device=8
+    used to put eight two-stream handles on one GPU.  Now lanes of 8..64 tile columns run on one stream (n = 1100: 9 tile
+    columns, column mode) and larger ones use event edges beyond six lanes (n = 8320: 65 tile columns): no poll-limit error,
+    and every chain's draws are those of the one-lane schedule."""
+    from andvaranaut_amd import GPMCMC, uniform
+
+    rng = np.random.default_rng(n)
+    priors = [st.uniform(loc=0, scale=1)] * 3
+    x = rng.random((n, 3))
+    y = (np.sin(3 * x[:, 0]) + x[:, 1] ** 2 - 0.5 * x[:, 2] + 0.05 * rng.standard_normal(n)).reshape(-1, 1)
+    out = {}
+    for k in (1, 8):
+        g = GPMCMC(kernel="RBF", noise=True, xconrevs=[uniform(p) for p in priors], yconrevs=[None], nx=3, ny=1, priors=priors,
+                   target=lambda r: np.zeros(1), verbose=False)
+        g.set_data(x, y)
+        out[k] = g.fit(method="mcmc_mean", return_data=True, draws=draws, tune=draws, chains=8, random_seed=2, chains_per_device=k,
+                       max_treedepth=3)
+    for name in ("l", "kv", "gv"):
+        assert np.array_equal(out[1].posterior[name], out[8].posterior[name]), name
+    assert np.array_equal(out[1].sample_stats["lp"], out[8].sample_stats["lp"])
 
 
 def test_batched_chains_have_the_draws_of_the_unbatched_schedule():

@@ -21,9 +21,8 @@ CSRC = os.path.join(ROOT, "andvaranaut_amd", "csrc")
 BUDGET = {
     "gemm_f64_kernel_sILb0ELb0ELb0E": (176, False),   # the plain 64x64-tile kernel, NT form: two workgroups per CU, tuned at 172
     "gemm_f64_kernel_sILb0ELb0ELb1E": (176, False),   # ... its k-flush instantiation
-    "gemm_f64_kernel_w": (256, False),                # 64x128 tiles (off by default): must still fit twice per CU
-    "syrk_thin_kernelILi128ELi2ELb1E": (128, False),
-    "syrk_thin_kernelILi256ELi4ELb1E": (192, False),
+    "syrk_thin_kernelILi128E": (128, False),
+    "syrk_thin_kernelILi256E": (192, False),
     "trsm_strip128_kernelILi1E": (224, False),        # (210 as tuned: two waves per SIMD)
 }
 

@@ -78,6 +78,52 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// ---- Who does what in the leaf's eight waves.  The waves meet through LDS counters, not barriers: a phase that waits for "every
+// helper" waits for a COUNT, and that count has to be the number of waves that execute the arriving side.  Round 5 got it wrong
+// once (waves 4..7 also ran the helpers' image load and counted as load arrivals: the helpers started on an incomplete image,
+// wrong factors now and then -- profiles/NOTES_r05.md item 6).  Every expected count below is derived from this ONE table, and
+// the checked flavour of the kernel (-DLEAF_CHECKED: tools/leaf_check.hip, tests/test_gpu_leaf_protocol.py) verifies at every
+// meeting point that the counters hold exactly what the protocol allows there and reports a mismatch through the info word.
+namespace roles {
+enum Role { CHAIN, HELPER, IDLE, INVERSE };
+constexpr int NWAVES = 8;
+constexpr Role ROLE[NWAVES] = {CHAIN, HELPER, HELPER, HELPER, IDLE, INVERSE, INVERSE, INVERSE};
+constexpr int count(Role r) {
+  int n = 0;
+  for (int w = 0; w < NWAVES; ++w) n += ROLE[w] == r ? 1 : 0;
+  return n;
+}
+constexpr int first(Role r) {
+  for (int w = 0; w < NWAVES; ++w)
+    if (ROLE[w] == r) return w;
+  return -1;
+}
+constexpr bool contiguous(Role r) {
+  for (int w = 0; w < NWAVES; ++w)
+    if ((ROLE[w] == r) != (w >= first(r) && w < first(r) + count(r))) return false;
+  return true;
+}
+constexpr int N_HELPERS = count(HELPER), N_INVERSE = count(INVERSE);
+constexpr int FIRST_HELPER = first(HELPER), FIRST_INVERSE = first(INVERSE);
+static_assert(count(CHAIN) == 1 && first(CHAIN) == 0, "wave 0 is the chain");
+static_assert(contiguous(HELPER) && contiguous(INVERSE), "a role's waves are consecutive (the dispatch below indexes them)");
+static_assert(N_HELPERS == 3 && N_INVERSE == 3, "the tile dealing (lt::, three waves) and the inverse's column dealing assume three each");
+// wave 4 * k + s runs on SIMD s: the chain has SIMD 0 to itself, inverse wave i shares a SIMD with helper i
+static_assert((FIRST_INVERSE - FIRST_HELPER) % 4 == 0 && FIRST_HELPER % 4 != 0, "helper i and inverse wave i share a SIMD, none shares the chain's");
+__device__ __forceinline__ bool is_helper(int wave) { return wave >= FIRST_HELPER && wave < FIRST_HELPER + N_HELPERS; }
+__device__ __forceinline__ bool is_inverse(int wave) { return wave >= FIRST_INVERSE && wave < FIRST_INVERSE + N_INVERSE; }
+constexpr int URGENT_ITERS = 6;  // iterations jb = 0 .. 5 have urgent tiles (the next block column's)
+}  // namespace roles
+[[maybe_unused]] constexpr int LEAF_PROTOCOL_INFO = -1000;  // checked flavour: info = LEAF_PROTOCOL_INFO - site on a protocol mismatch
+#ifdef LEAF_CHECKED
+#define LEAF_EXPECT(cond, site)                                                              \
+  do {                                                                                       \
+    if (!(cond) && (threadIdx.x & 63) == 0) atomicMin(info, LEAF_PROTOCOL_INFO - (site));    \
+  } while (0)
+#else
+#define LEAF_EXPECT(cond, site)
+#endif
+
 // 1/x for normal x: hardware seed (v_rcp_f64) + two Newton steps (~1 ulp).
 __device__ __forceinline__ double fast_rcp(double x) {
   double y = __builtin_amdgcn_rcp(x);
@@ -329,10 +375,7 @@ __device__ __forceinline__ constexpr int mt_off(int b, int c) { return (b * (b +
 // of a wave holds M[16 jb + n][16 kb + 4 q + s], s = 0..3, so a tile is two runs of 64 lanes x 2 doubles: s < 2, then s >= 2.
 // A wave's operand load is then 1 KB of consecutive addresses (round 5; row-major until then: every quarter-wave touched 16
 // rows, and the strip was bound by the texture addresser, not by memory or MFMA).
-__device__ __forceinline__ int minv_index(int row, int col) {
-  const int jb = row >> 4, n = row & 15, kb = col >> 4, c = col & 15;
-  return (jb * 8 + kb) * 256 + (c & 2) * 64 + ((c >> 2) * 16 + n) * 2 + (c & 1);
-}
+// (minv_index itself lives in migp_kernels.h: the fused strip + update kernel of thin_f64.hip writes the same order)
 
 __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, long lda, double* __restrict__ minv,
                                                     int col0, int* __restrict__ info, double* smem, double* yrow) {
@@ -431,7 +474,9 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
       // (the identity rows go into buffer jb & 3: the inverse's waves run on their own and have to be through with block row
       // jb - 4, the buffer's previous user -- they always are; the check is one LDS read)
       if (jb >= 4) {
-        while (sync_w[3] < 3 * (jb - 3)) __builtin_amdgcn_s_sleep(1);
+        while (sync_w[3] < roles::N_INVERSE * (jb - 3)) __builtin_amdgcn_s_sleep(1);
+        // (the inverse's waves have seen blocks 0 .. jb - 1 published: at most that many block rows each)
+        LEAF_EXPECT(sync_w[3] <= roles::N_INVERSE * jb, 1);
       }
       // X~ of the rows below the block (and the identity rows), the pivots and their reciprocals first: the updates wait for
       // them; the block's own rows are read by nobody before the normalisation
@@ -510,31 +555,36 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
       else iteration(std::integral_constant<int, 2>(), jb);
       if (jb + 1 < LEAF / SB) {
         if (jb == 0) {  // the helpers' part of the LDS image (every column right of block 0)
-          while (sync_w[2] < 3) __builtin_amdgcn_s_sleep(1);
+          while (sync_w[2] < roles::N_HELPERS) __builtin_amdgcn_s_sleep(1);
           wave_lds_fence();
+          LEAF_EXPECT(sync_w[2] == roles::N_HELPERS, 2);
         }
         update_diag_tile(jb);
         wave_lds_fence();
         LEAF_PROBE(8 * jb + 4);
-        if (jb <= 5) {
-          while (sync_w[1] < 3 * (jb + 1)) {}
+        if (jb < roles::URGENT_ITERS) {
+          while (sync_w[1] < roles::N_HELPERS * (jb + 1)) {}
           wave_lds_fence();
+          // (no helper passes its wait for block jb + 1 before this wave publishes it: exactly the arrivals of blocks 0 .. jb)
+          LEAF_EXPECT(sync_w[1] == roles::N_HELPERS * (jb + 1), 3);
         }
         LEAF_PROBE(8 * jb + 5);
       }
     }
   } else {
     // ---------------------------------------------------------------- the helpers
-    const int t = tid - 64;
-    if (wave <= 3) {  // (the helpers; the inverse's waves start at the first published block)
+    const int t = tid - 64 * roles::FIRST_HELPER;
+    constexpr int NHT = 64 * roles::N_HELPERS;  // helper threads
+    if (roles::is_helper(wave)) {  // (the helpers; the inverse's waves start at the first published block)
       // the LDS image right of column block 0: row block b holds 16 rows x 8 b pieces of 16 bytes there
-      double2_t v[21];  // sum over row blocks of ceil(128 b / 192)
+      double2_t v[21];  // sum over row blocks of ceil(128 b / NHT)
+      static_assert(NHT == 192, "v[] is sized for 192 loading threads");
       int u = 0;
 #pragma unroll
       for (int bb = 1; bb < 8; ++bb) {
         const int per = 8 * bb, cnt = 16 * per;
 #pragma unroll
-        for (int idx0 = 0; idx0 < cnt; idx0 += 192) {
+        for (int idx0 = 0; idx0 < cnt; idx0 += NHT) {
           const int idx = idx0 + t;
           if (idx < cnt) v[u] = *reinterpret_cast<const double2_t*>(Ablk + (long)(16 * bb + idx / per) * lda + 16 + 2 * (idx % per));
           ++u;
@@ -545,7 +595,7 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
       for (int bb = 1; bb < 8; ++bb) {
         const int per = 8 * bb, cnt = 16 * per;
 #pragma unroll
-        for (int idx0 = 0; idx0 < cnt; idx0 += 192) {
+        for (int idx0 = 0; idx0 < cnt; idx0 += NHT) {
           const int idx = idx0 + t;
           if (idx < cnt) *reinterpret_cast<double2_t*>(S + soff(16 * bb + idx / per) + 16 + 2 * (idx % per)) = v[u];
           ++u;
@@ -553,8 +603,9 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
       }
       wave_lds_fence();
       if (lane == 0) lds_add(sync_a + 2, 1);
-      while (sync_w[2] < 3) __builtin_amdgcn_s_sleep(1);
+      while (sync_w[2] < roles::N_HELPERS) __builtin_amdgcn_s_sleep(1);
       wave_lds_fence();
+      LEAF_EXPECT(sync_w[2] == roles::N_HELPERS, 4);
     }
     LEAF_PROBE(62);
     // Register-resident trailing tiles (see namespace lt).  Per phase a wave reads one operand set (4 doubles per lane) per
@@ -634,7 +685,7 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
       double* dst[6];
 #pragma unroll
       for (int u = 0; u < 6; ++u) {
-        const int it = t + 192 * u;
+        const int it = t + NHT * u;
         const int r = c0 + (it >> 3), c2 = c0 + 2 * (it & 7);
         const bool in = it < npiece && c2 <= r;
         full[u] = in && c2 + 1 <= r;
@@ -745,8 +796,10 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
       constexpr int JB = decltype(JBc)::value, NB = LEAF / SB;
       const double4_t z4 = {0.0, 0.0, 0.0, 0.0};
       if constexpr (JB + 1 < NB) {
-        while (sync_w[3] < 3 * (JB + 1)) __builtin_amdgcn_s_sleep(1);
+        while (sync_w[3] < roles::N_INVERSE * (JB + 1)) __builtin_amdgcn_s_sleep(1);
         wave_lds_fence();
+        // (a faster wave may have delivered block row JB + 1 already -- not JB + 2: that needs this wave's row JB + 1)
+        LEAF_EXPECT(sync_w[3] < roles::N_INVERSE * (JB + 2), 5);
 #pragma unroll
         for (int q = 0; q < 3; ++q) tsum[q] = tbulk[q];
         inv_acc(std::integral_constant<int, JB + 1>(), Wc, JBc, std::integral_constant<int, JB + 1>(), tsum);
@@ -764,8 +817,10 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
         constexpr int JB = decltype(JBc)::value;
         while (sync_w[0] < JB + 1) __builtin_amdgcn_s_sleep(1);  // (a tight spin takes issue slots from the inverse wave on this SIMD)
         wave_lds_fence();
+        // (the chain publishes block JB + 1 only behind this wave's urgent arrival for block JB, while there are urgent tiles)
+        LEAF_EXPECT(JB < roles::URGENT_ITERS ? sync_w[0] == JB + 1 : sync_w[0] <= LEAF / SB, 6);
         LEAF_PROBE(64 + 8 * JB + 0);
-        if constexpr (JB <= 5) {
+        if constexpr (JB < roles::URGENT_ITERS) {
           trailing(JBc, Wc, std::integral_constant<int, 0>());
           wave_lds_fence();
           if (lane == 0) lds_add(sync_a + 1, 1);
@@ -790,6 +845,8 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
         constexpr int JB = decltype(JBc)::value;
         while (sync_w[0] < JB + 1) __builtin_amdgcn_s_sleep(1);
         wave_lds_fence();
+        // (the chain re-uses identity-row buffer JB & 3 for block JB + 4 only behind this wave's block row JB)
+        LEAF_EXPECT(sync_w[0] <= JB + 4 && sync_w[0] <= LEAF / SB, 7);
         LEAF_PROBE(128 + 8 * JB + 0);
         inv_final(JBc, Wc);
         LEAF_PROBE(128 + 8 * JB + 1);
@@ -797,15 +854,23 @@ __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, lo
         LEAF_PROBE(128 + 8 * JB + 2);
       });
     };
-    if (wave == 1) helper(std::integral_constant<int, 0>());
-    else if (wave == 2) helper(std::integral_constant<int, 1>());
-    else if (wave == 3) helper(std::integral_constant<int, 2>());
-    else if (wave == 5) inverse_worker(std::integral_constant<int, 0>());
-    else if (wave == 6) inverse_worker(std::integral_constant<int, 1>());
-    else if (wave == 7) inverse_worker(std::integral_constant<int, 2>());
-    // (wave 4 would share SIMD 0 with the chain: it does nothing)
+    if (wave == roles::FIRST_HELPER) helper(std::integral_constant<int, 0>());
+    else if (wave == roles::FIRST_HELPER + 1) helper(std::integral_constant<int, 1>());
+    else if (wave == roles::FIRST_HELPER + 2) helper(std::integral_constant<int, 2>());
+    else if (wave == roles::FIRST_INVERSE) inverse_worker(std::integral_constant<int, 0>());
+    else if (wave == roles::FIRST_INVERSE + 1) inverse_worker(std::integral_constant<int, 1>());
+    else if (wave == roles::FIRST_INVERSE + 2) inverse_worker(std::integral_constant<int, 2>());
+    // (the idle wave would share SIMD 0 with the chain: it does nothing)
   }
   LEAF_PROBE(63);
+#ifdef LEAF_CHECKED
+  // every wave is through: the counters hold exactly one arrival per executing wave and phase
+  __syncthreads();
+  LEAF_EXPECT(sync_w[0] == LEAF / SB, 8);
+  LEAF_EXPECT(sync_w[1] == roles::N_HELPERS * roles::URGENT_ITERS, 9);
+  LEAF_EXPECT(sync_w[2] == roles::N_HELPERS, 10);
+  LEAF_EXPECT(sync_w[3] == roles::N_INVERSE * (LEAF / SB), 11);
+#endif
   // Last tile column of an evaluation: the only rows below are the y^T row block (one non-zero row), so the forward
   // solve of these 128 columns, beta = y M^T, is done here against the inverse that is still in LDS -- the strip launch
   // for that block (6 us of launch and round trips for 16k flops) is skipped.

@@ -98,6 +98,13 @@ hipError_t launch_potrf_leaf128(double* Ablk, long lda, double* minv, int col0, 
 constexpr int SIGNAL_TIMEOUT_INFO = -99;
 hipError_t launch_signal_write_wait(unsigned* wr, const unsigned* wt, unsigned val, int* info, hipStream_t stream, int nb = 1,
                                     int sinfo = 0, int poll_log2 = 22);
+// element (row, col) of a 128 x 128 block kept as 16x16 tiles in the strip kernel's MFMA operand order (leaf_f64.hip: the leaf's
+// inverse, the strips' operand-order copies of their first rows)
+__device__ __forceinline__ int minv_index(int row, int col) {
+  const int jb = row >> 4, n = row & 15, kb = col >> 4, c = col & 15;
+  return (jb * 8 + kb) * 256 + (c & 2) * 64 + ((c >> 2) * 16 + n) * 2 + (c & 1);
+}
+
 // ---------------------------------------------------------------- thin_f64.hip
 // C[ti, tj] -= P[ti] P[tj]^T over the lower trapezoid of mt x nt tiles (tj <= ti), k = 128 (nt <= 2) or k = 256 (nt = 1):
 // 16-row x 64-column workgroups, for the panel chain's short updates.  wr (optional): workgroup 0 raises *wr to val
@@ -105,6 +112,17 @@ hipError_t launch_signal_write_wait(unsigned* wr, const unsigned* wt, unsigned v
 // them (launch_trsm_strip128's lsw); k = 256: the B operand's first 128 k from lsw, the other 128 from lsw2 (two strips' copies)
 hipError_t launch_syrk_thin(const double* P, double* C, long ld, int mt, int nt, int k, hipStream_t stream, const Batch* bt,
                             unsigned* wr, unsigned val, const double* lsw, const double* lsw2 = nullptr);
+
+// The strip of tile column j and the k = 128 / 256 update of column j + 1 behind it in ONE launch (thin_f64.hip): B = element (tile
+// row j + 1, column j), m rows, solved in place against the leaf inverse `minv`; C = element (tile row j + 1, column j + 1) takes
+// -= [P_(j-1) |] X times the rows of tile row j + 1 of the same.  k = 256: Pprev = element (tile row j + 1, column j - 1) and lsw_prev =
+// the block of column j - 1's operand-order copy that holds tile row j + 1.  lsw: this strip's copy (lsw_blocks >= 8 row groups);
+// flags: FUSE_FLAG_WORDS words per problem, tag: a value no earlier launch on these words used; a poll that gives up puts
+// SIGNAL_TIMEOUT_INFO into info.  Same bits as launch_trsm_strip128 + launch_syrk_thin.
+constexpr int FUSE_PRODUCERS = 8, FUSE_FLAG_WORDS = 8;
+hipError_t launch_strip_thin(const double* minv, double* B, const double* Pprev, double* C, long ld, int m, int k, double* lsw,
+                             const double* lsw_prev, int lsw_blocks, unsigned* flags, unsigned tag, int* info, int poll_log2,
+                             hipStream_t stream, const Batch* bt = nullptr);
 
 // ---------------------------------------------------------------- leaf_f64.hip (continued)
 // X * L^T = B in place on the m x 128 panel B (m multiple of 16, ldb even) as X = B * M^T with the leaf's inverse M.

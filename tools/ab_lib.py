@@ -1,5 +1,6 @@
 """A/B of whole library BUILDS on one box: alternating subprocesses, one per (library, round).
-    python tools/ab_lib.py "4096 8 RBF" "8192 8 RBF" -- tools/ab/lib_a.so tools/ab/lib_b.so
+    python tools/ab_lib.py "4096 8 RBF" "8192 8 RBF" -- tools/ab/r05/andvaranaut_amd/libmi_gp.so andvaranaut_amd/libmi_gp.so
+(a library given as <root>/andvaranaut_amd/libmi_gp.so with a bench.py beside the package runs through THAT root's Python package)
 Each subprocess loads the given libmi_gp.so (andvaranaut_amd._lib.LIB_PATH), evaluates the LML a few times and prints the
 median; three rounds per library, interleaved, so that box-to-box and drift effects cancel."""
 import os
@@ -12,9 +13,11 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 WORKER = r'''
 import os, sys, time
 import numpy as np
-sys.path.insert(0, sys.argv[1])
+lib = os.path.abspath(sys.argv[2])
+own = os.path.dirname(os.path.dirname(lib))  # <root>/andvaranaut_amd/libmi_gp.so: that root's Python package (an older C-ABI)
+sys.path.insert(0, own if os.path.basename(os.path.dirname(lib)) == "andvaranaut_amd" and os.path.exists(os.path.join(own, "bench.py")) else sys.argv[1])
 import andvaranaut_amd._lib as L
-L.LIB_PATH = os.path.abspath(sys.argv[2])
+L.LIB_PATH = lib
 from andvaranaut_amd import MiGP
 from bench import synth_problem, theta_sequence
 N, d, kern = int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]

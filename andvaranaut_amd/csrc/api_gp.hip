@@ -49,11 +49,7 @@ struct mi_gp_handle {
   int u_leaf_done, u_node_done[12]; // tile columns whose leaf block of U is done / full nodes done per level
   int thin_max_wg;                  // option 32: in-panel updates of at most this many 16-row x 128-column slices (k = 128, at most
                                     // THIN_MAX_COLS tile columns) run on the thin kernel (thin_f64.hip); 0: never
-  int fuse;                         // option 41: column mode's strip and the thin update behind it run as ONE launch (thin_f64.hip
-                                    // strip_thin_kernel; default 1) -- scheduling only; cleared with the polls when one gives up
-  unsigned* fuse_dev;               // its flag words [FUSE_FLAG_WORDS] (a batch: b_fuse_dev, FUSE_FLAG_WORDS per problem)
-  unsigned* b_fuse_dev;
-  unsigned fuse_tag;                // value of the flag words of the last fused launch (never 0: the words start zeroed)
+  int rl_group1;                    // option 42: ... and of a SINGLE evaluation on two streams (default 1: one launch per column)
   int rl_group;                     // option 38: column mode of a BATCH applies the main stream's k = 128 updates to the far columns in
                                     // k-segmented launches of this many columns (same bits, the trailing matrices read and written once per group)
   int rl_cols;                      // option 37: the last rl_cols tile columns are factored COLUMN BY COLUMN (cholesky(): column mode); 0: never
@@ -138,7 +134,6 @@ static void release_handle(mi_gp_handle* h) {
   if (h->pstream) (void)hipStreamSynchronize(h->pstream);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   (void)hipFree(h->theta_dev); (void)hipFree(h->dinv_dev); (void)hipFree(h->info_dev); (void)hipFree(h->sig_dev);
-  (void)hipFree(h->fuse_dev); (void)hipFree(h->b_fuse_dev);
   (void)hipFree(h->alpha_dev); (void)hipFree(h->part_dev); (void)hipFree(h->gxs_dev);
   (void)hipFree(h->lr_part_dev); (void)hipFree(h->lr_sync_dev); (void)hipFree(h->b_lr_part_dev); (void)hipFree(h->b_lr_sync_dev);
   (void)hipFree(h->b_theta_dev); (void)hipFree(h->b_dinv_dev); (void)hipFree(h->b_alpha_dev); (void)hipFree(h->b_part_dev);
@@ -252,8 +247,7 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   h->demoted = false;
   h->thin_max_wg = 2048;
   h->rl_cols = 24;
-  h->fuse = 1;
-  h->fuse_tag = 0;
+  h->rl_group1 = 1;
   h->rl_group = 8;
   h->ext_rows = 32;
   h->done_col = h->done_slot = -1;
@@ -279,8 +273,6 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   if (e == hipSuccess) e = hipMalloc(&h->info_dev, sizeof(int) * 4);
   if (e == hipSuccess) e = hipMalloc(&h->sig_dev, sizeof(unsigned) * SIG_SLOTS);
   if (e == hipSuccess) e = hipMemset(h->sig_dev, 0, sizeof(unsigned) * SIG_SLOTS);
-  if (e == hipSuccess) e = hipMalloc(&h->fuse_dev, sizeof(unsigned) * FUSE_FLAG_WORDS);
-  if (e == hipSuccess) e = hipMemset(h->fuse_dev, 0, sizeof(unsigned) * FUSE_FLAG_WORDS);
   if (e == hipSuccess) e = hipMalloc(&h->lr_part_dev, sizeof(double) * 2 * LML_REDUCE_BLOCKS);
   if (e == hipSuccess) e = hipMalloc(&h->lr_sync_dev, sizeof(unsigned));
   if (e == hipSuccess) e = hipMemset(h->lr_sync_dev, 0, sizeof(unsigned));
@@ -358,7 +350,7 @@ extern "C" int mi_gp_set_option(mi_gp_handle* h, int what, int value) {
   else if (what == 35) h->ext_rows = value < 0 ? 0 : value;
   else if (what == 37) h->rl_cols = value < 0 ? 0 : value;
   else if (what == 38) h->rl_group = value < 1 ? 1 : value > 8 ? 8 : value;
-  else if (what == 41) h->fuse = value ? 1 : 0;
+  else if (what == 42) h->rl_group1 = value < 1 ? 1 : value > 8 ? 8 : value;
   else if (what == 9) h->tail_small = value ? 1 : 0;
   else {
     snprintf(h->err, sizeof(h->err), "mi_gp_set_option: unknown option %d", what);
@@ -393,7 +385,7 @@ extern "C" int mi_gp_get_option(mi_gp_handle* h, int what, int* value) {
     case 35: *value = h->ext_rows; break;
     case 37: *value = h->rl_cols; break;
     case 38: *value = h->rl_group; break;
-    case 41: *value = h->fuse; break;
+    case 42: *value = h->rl_group1; break;
     case 40: *value = h->demoted ? 1 : 0; break;
     default:
       snprintf(h->err, sizeof(h->err), "mi_gp_get_option: unknown option %d", what);
@@ -655,7 +647,7 @@ static hipError_t chol_columns(mi_gp_handle* h, double* A, long lda, int ntr, in
     return se;
   };
   double* lsw0 = h->dinv_dev + (size_t)h->ntc * MINV_ELEMS;
-  const int group = (h->btp && h->btp->nb > 1) ? h->rl_group : 1;
+  const int group = (h->btp && h->btp->nb > 1) ? h->rl_group : (two ? h->rl_group1 : 1);
   int seg0 = cs;  // grouped schedule: first column (k-segment) the columns behind the chain's next one have not had yet
   if (two && t_pending) CKC(t_signal((cs + 1) % 3));  // polled by leaf cs: the index leaf j polls is (j - 2) mod 3 = (j + 1) mod 3
   for (int j = cs; j < ntc; ++j) {
@@ -680,23 +672,11 @@ static hipError_t chol_columns(mi_gp_handle* h, double* A, long lda, int ntr, in
     CKC(launch_potrf_leaf128(blk, lda, dinv, j * 128, h->info_dev, P, m == 128 ? blk + 128 * lda : nullptr, h->btp,
                              polls && tslot[pidx] >= 0 ? h->sig_dev + tslot[pidx] : nullptr, h->sig_epoch, h->poll_limit_log2,
                              sslot >= 0 ? h->sig_dev + sslot : nullptr));
-    // strip j and the thin update of column j + 1 behind it as ONE launch (option 41; same arithmetic per element: scheduling only)
-    const bool fused = h->fuse && thin_ok && m > 128 && j + 1 < ntc;
-    if (fused && polls && tslot[pidx] < 0) CKC(hipStreamWaitEvent(P, tev[pidx], 0));  // (event edges: in front of the update's launch)
-    if (fused) {
-      const bool k2 = j - 1 >= cs;
-      if (++h->fuse_tag == 0) h->fuse_tag = 1;
-      CKC(launch_strip_thin(dinv, blk + 128 * lda, k2 ? A + (long)(j + 1) * 128 * lda + (long)(j - 1) * 128 : nullptr,
-                            A + (long)(j + 1) * 128 * lda + (long)(j + 1) * 128, lda, m, k2 ? 256 : 128, lswj,
-                            k2 ? lsw0 + (size_t)(2 * ((j - 1) & 1) + 1) * MINV_ELEMS : nullptr, 16,
-                            h->btp ? h->b_fuse_dev : h->fuse_dev, h->fuse_tag, h->info_dev, h->poll_limit_log2, P, h->btp));
-    } else if (m > 128) {
-      CKC(launch_trsm_strip128(dinv, blk + 128 * lda, lda, m, P, h->btp, h->btp ? h->btp->sK : 0, lsw_out ? lswj : nullptr, 16));
-    }
-    if (!fused && polls && tslot[pidx] < 0) CKC(hipStreamWaitEvent(P, tev[pidx], 0));
+    if (m > 128) CKC(launch_trsm_strip128(dinv, blk + 128 * lda, lda, m, P, h->btp, h->btp ? h->btp->sK : 0, lsw_out ? lswj : nullptr, 16));
+    if (polls && tslot[pidx] < 0) CKC(hipStreamWaitEvent(P, tev[pidx], 0));
     tslot[pidx] = -1;
     tev_set[pidx] = false;
-    if (j + 1 < ntc && !fused) {
+    if (j + 1 < ntc) {
       // the next column <- this one and (from the second column of the mode on) the one before it
       const bool k2 = j - 1 >= cs;
       const int k0 = k2 ? j - 1 : j, kw = k2 ? 2 : 1, mt = ntr - j - 1;
@@ -1072,9 +1052,8 @@ static int run_evaluation(mi_gp_handle* h, int what) {
 // edges have no polls: the test hook, or a caller who re-armed option 26 in between) is the caller's error -2.
 static int poll_timeout(mi_gp_handle* h, int attempt) {
   HCK(hipStreamSynchronize(h->pstream), "panel stream sync");  // (its remaining launches ran through: every later poll gave up at once)
-  if (attempt == 0 && (h->use_smo != 0 || h->fuse != 0)) {
+  if (attempt == 0 && h->use_smo != 0) {
     h->use_smo = 0;
-    h->fuse = 0;  // (the fused strip + update launch polls too: inside one launch, but whatever stopped a poll is not trusted again)
     h->demoted = true;
     snprintf(h->err, sizeof(h->err), "a cross-stream signal was not seen within its poll limit: this handle's cross-stream edges are "
                                      "events from now on (option 26 = 0), the evaluation was repeated");
@@ -1350,8 +1329,8 @@ extern "C" int mi_gp_set_batch(mi_gp_handle* h, const mi_gp_batch_buffers* b) {
   if (b->count > h->batch_cap) {
     (void)hipStreamSynchronize(h->stream);
     (void)hipFree(h->b_theta_dev); (void)hipFree(h->b_dinv_dev); (void)hipFree(h->b_alpha_dev); (void)hipFree(h->b_part_dev);
-    (void)hipFree(h->b_info_dev); (void)hipFree(h->b_lr_part_dev); (void)hipFree(h->b_lr_sync_dev); (void)hipFree(h->b_fuse_dev);
-    h->b_lr_part_dev = nullptr; h->b_lr_sync_dev = nullptr; h->b_fuse_dev = nullptr;
+    (void)hipFree(h->b_info_dev); (void)hipFree(h->b_lr_part_dev); (void)hipFree(h->b_lr_sync_dev);
+    h->b_lr_part_dev = nullptr; h->b_lr_sync_dev = nullptr;
     if (h->b_grad_host) (void)hipHostFree(h->b_grad_host);
     if (h->b_out_host) (void)hipHostFree(h->b_out_host);
     if (h->b_theta_host) (void)hipHostFree(h->b_theta_host);
@@ -1367,8 +1346,6 @@ extern "C" int mi_gp_set_batch(mi_gp_handle* h, const mi_gp_batch_buffers* b) {
     HCK(hipMalloc(&h->b_lr_part_dev, sizeof(double) * 2 * LML_REDUCE_BLOCKS * k), "batch scratch");
     HCK(hipMalloc(&h->b_lr_sync_dev, sizeof(unsigned) * k), "batch scratch");
     HCK(hipMemset(h->b_lr_sync_dev, 0, sizeof(unsigned) * k), "batch scratch");
-    HCK(hipMalloc(&h->b_fuse_dev, sizeof(unsigned) * FUSE_FLAG_WORDS * k), "batch scratch");
-    HCK(hipMemset(h->b_fuse_dev, 0, sizeof(unsigned) * FUSE_FLAG_WORDS * k), "batch scratch");
     HCK(hipHostMalloc(&h->b_grad_host, sizeof(double) * k * h->ntheta), "batch scratch");
     HCK(hipHostMalloc(&h->b_out_host, sizeof(double) * 16 * k), "batch scratch");
     HCK(hipHostMalloc(&h->b_theta_host, sizeof(double) * k * h->ntheta), "batch scratch");

@@ -375,7 +375,7 @@ __device__ __forceinline__ constexpr int mt_off(int b, int c) { return (b * (b +
 // of a wave holds M[16 jb + n][16 kb + 4 q + s], s = 0..3, so a tile is two runs of 64 lanes x 2 doubles: s < 2, then s >= 2.
 // A wave's operand load is then 1 KB of consecutive addresses (round 5; row-major until then: every quarter-wave touched 16
 // rows, and the strip was bound by the texture addresser, not by memory or MFMA).
-// (minv_index itself lives in migp_kernels.h: the fused strip + update kernel of thin_f64.hip writes the same order)
+// (minv_index itself lives in migp_kernels.h)
 
 __device__ __forceinline__ void potrf_leaf128_body(double* __restrict__ Ablk, long lda, double* __restrict__ minv,
                                                     int col0, int* __restrict__ info, double* smem, double* yrow) {

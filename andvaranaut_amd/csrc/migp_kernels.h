@@ -113,17 +113,6 @@ __device__ __forceinline__ int minv_index(int row, int col) {
 hipError_t launch_syrk_thin(const double* P, double* C, long ld, int mt, int nt, int k, hipStream_t stream, const Batch* bt,
                             unsigned* wr, unsigned val, const double* lsw, const double* lsw2 = nullptr);
 
-// The strip of tile column j and the k = 128 / 256 update of column j + 1 behind it in ONE launch (thin_f64.hip): B = element (tile
-// row j + 1, column j), m rows, solved in place against the leaf inverse `minv`; C = element (tile row j + 1, column j + 1) takes
-// -= [P_(j-1) |] X times the rows of tile row j + 1 of the same.  k = 256: Pprev = element (tile row j + 1, column j - 1) and lsw_prev =
-// the block of column j - 1's operand-order copy that holds tile row j + 1.  lsw: this strip's copy (lsw_blocks >= 8 row groups);
-// flags: FUSE_FLAG_WORDS words per problem, tag: a value no earlier launch on these words used; a poll that gives up puts
-// SIGNAL_TIMEOUT_INFO into info.  Same bits as launch_trsm_strip128 + launch_syrk_thin.
-constexpr int FUSE_PRODUCERS = 8, FUSE_FLAG_WORDS = 8;
-hipError_t launch_strip_thin(const double* minv, double* B, const double* Pprev, double* C, long ld, int m, int k, double* lsw,
-                             const double* lsw_prev, int lsw_blocks, unsigned* flags, unsigned tag, int* info, int poll_log2,
-                             hipStream_t stream, const Batch* bt = nullptr);
-
 // ---------------------------------------------------------------- leaf_f64.hip (continued)
 // X * L^T = B in place on the m x 128 panel B (m multiple of 16, ldb even) as X = B * M^T with the leaf's inverse M.
 // lsw (optional): the first lsw_blocks 16-row groups of X are also written there in MFMA operand order (128 rows per 16384

@@ -194,11 +194,7 @@ MI_GP_API int mi_gp_predict_grad(mi_gp_handle* h, const double* Xnew_dev, int m,
  *   38 column mode of a BATCH: the main stream applies its k = 128 updates to the columns behind the chain's next one in
  *      k-segmented launches of this many columns (default 8; 1: one launch per column as for a single evaluation).  The tile
  *      takes every 128-column partial sum as a launch of its own would round it: same bits, scheduling only.
- *   41 column mode runs the strip of a tile column and the thin update of the next column behind it as ONE launch (default 1; 0: two
- *      launches): the eight workgroups that own the first 128 rows publish them to the others inside the launch (write-through
- *      stores, one flag word each, bounded polls -- a poll that gives up is handled like option 26's).  Same arithmetic per element:
- *      scheduling only.
- * 8, 14, 16, 18, 19, 21, 24, 26, 27, 30, 31, 38 and 41 only change scheduling (bit-identical results); 20 moves tiles between the
+ * 8, 14, 16, 18, 19, 21, 24, 26, 27, 30, 31 and 38 only change scheduling (bit-identical results); 20 moves tiles between the
  * two GEMM kernels (same k order); 2, 4-7, 9, 32, 35 and 37 regroup sums (agreement to rounding), and so does 0 where it changes
  * the super-panel width (20 to 60 tile columns).
  * Unknown ids return -1.  (Round 1's options 1, 3, 10-13 -- GEMM variants, hipGraph replay, persistent bulk kernels,

@@ -101,7 +101,7 @@ t0 = time.perf_counter()
 v2 = gp.lml(theta)
 t_second = time.perf_counter() - t0
 ref = orc.lml(X, y, ["Matern52"], [], theta)
-print("RESULT", repr(v), repr(v2), repr(ref), gp.info, demoted_at_create, gp.get_option(40), gp.get_option(26), t_create, t_first, t_second)
+print("RESULT", repr(float(v)), repr(float(v2)), repr(float(ref)), gp.info, demoted_at_create, gp.get_option(40), gp.get_option(26), t_create, t_first, t_second)
 gp.close()
 """
 
@@ -224,13 +224,13 @@ def test_column_mode_and_extended_panels_return_the_same_bits_on_every_schedule(
     v0, g0 = gp.lml_grad(theta)
     ref = orc.lml(X, y, ["Matern52"], [], theta)
     assert abs(v0 - ref) <= 1e-10 * abs(ref)
-    for opts in ([(0, 0)], [(0, 2)], [(26, 0)], [(26, 1)], [(26, 0), (0, 2)], [(21, 16)], [(30, 0)], [(41, 0)], [(41, 0), (0, 0)]):
+    for opts in ([(0, 0)], [(0, 2)], [(26, 0)], [(26, 1)], [(26, 0), (0, 2)], [(21, 16)], [(30, 0)]):
         for k, v in opts:
             gp.set_option(k, v)
         v1, g1 = gp.lml_grad(theta)
         assert v1 == v0 and np.array_equal(g1, g0), opts
         assert gp.lml(theta) == v0, opts
-        for k, v in {0: 1, 26: 2, 21: 8, 30: 16, 41: 1}.items():
+        for k, v in {0: 1, 26: 2, 21: 8, 30: 16}.items():
             gp.set_option(k, v)
     gp.close()
 

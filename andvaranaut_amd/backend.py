@@ -373,10 +373,10 @@ class MiGP:
         self.lib.mi_gp_set_profiling(self.h, int(level))
 
     def timers(self):
-        out = (ctypes.c_double * 13)()
-        self.lib.mi_gp_timers(self.h, out, 13)
+        out = (ctypes.c_double * 14)()
+        self.lib.mi_gp_timers(self.h, out, 14)
         keys = ["assemble_ms", "cholesky_ms", "reduce_ms", "total_ms", "gemm_ms", "gemm_flops", "gemm_launches",
-                "trtri_ms", "lauum_ms", "contract_ms", "gemm_b_ms", "gemm_b_flops", "gemm_b_launches"]
+                "trtri_ms", "lauum_ms", "contract_ms", "gemm_b_ms", "gemm_b_flops", "gemm_b_launches", "enqueue_ms"]
         return dict(zip(keys, list(out)))
 
     def close(self):

@@ -1,6 +1,7 @@
 // Handle-level C-ABI (include/mi_gp.h): covariance assembly -> blocked right-looking Cholesky ->
 // log marginal likelihood.  Replaces what pm.find_MAP / pm.sample evaluate per step through
 // pm.gp.Marginal.marginal_likelihood (gpmcmc.py:321-323, 345, 351).
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -49,7 +50,6 @@ struct mi_gp_handle {
   int u_leaf_done, u_node_done[12]; // tile columns whose leaf block of U is done / full nodes done per level
   int thin_max_wg;                  // option 32: in-panel updates of at most this many 16-row x 128-column slices (k = 128, at most
                                     // THIN_MAX_COLS tile columns) run on the thin kernel (thin_f64.hip); 0: never
-  int rl_group1;                    // option 42: ... and of a SINGLE evaluation on two streams (default 1: one launch per column)
   int rl_group;                     // option 38: column mode of a BATCH applies the main stream's k = 128 updates to the far columns in
                                     // k-segmented launches of this many columns (same bits, the trailing matrices read and written once per group)
   int rl_cols;                      // option 37: the last rl_cols tile columns are factored COLUMN BY COLUMN (cholesky(): column mode); 0: never
@@ -98,6 +98,7 @@ struct mi_gp_handle {
   double gemm_flops_acc;
   double t_assemble_ms, t_chol_ms, t_reduce_ms, t_gemm_ms, t_total_ms, gemm_flops, n_gemm;
   double t_trtri_ms, t_lauum_ms, t_contract_ms;
+  double t_enqueue_ms;  // host time of enqueueing the last single evaluation (always measured: two clock reads)
   double t_gemm_big_ms, gemm_big_flops, n_gemm_big;  // the 128x128-tile kernel only
   // batched evaluation (mi_gp_set_batch / mi_gp_lml_batch / mi_gp_lml_grad_batch): while a batch runs, buf / the scratch
   // pointers above point at the batch's arrays and bt carries the strides; nullptr / nb = 1 otherwise
@@ -247,7 +248,6 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   h->demoted = false;
   h->thin_max_wg = 2048;
   h->rl_cols = 24;
-  h->rl_group1 = 1;
   h->rl_group = 8;
   h->ext_rows = 32;
   h->done_col = h->done_slot = -1;
@@ -350,7 +350,6 @@ extern "C" int mi_gp_set_option(mi_gp_handle* h, int what, int value) {
   else if (what == 35) h->ext_rows = value < 0 ? 0 : value;
   else if (what == 37) h->rl_cols = value < 0 ? 0 : value;
   else if (what == 38) h->rl_group = value < 1 ? 1 : value > 8 ? 8 : value;
-  else if (what == 42) h->rl_group1 = value < 1 ? 1 : value > 8 ? 8 : value;
   else if (what == 9) h->tail_small = value ? 1 : 0;
   else {
     snprintf(h->err, sizeof(h->err), "mi_gp_set_option: unknown option %d", what);
@@ -385,7 +384,6 @@ extern "C" int mi_gp_get_option(mi_gp_handle* h, int what, int* value) {
     case 35: *value = h->ext_rows; break;
     case 37: *value = h->rl_cols; break;
     case 38: *value = h->rl_group; break;
-    case 42: *value = h->rl_group1; break;
     case 40: *value = h->demoted ? 1 : 0; break;
     default:
       snprintf(h->err, sizeof(h->err), "mi_gp_get_option: unknown option %d", what);
@@ -647,7 +645,7 @@ static hipError_t chol_columns(mi_gp_handle* h, double* A, long lda, int ntr, in
     return se;
   };
   double* lsw0 = h->dinv_dev + (size_t)h->ntc * MINV_ELEMS;
-  const int group = (h->btp && h->btp->nb > 1) ? h->rl_group : (two ? h->rl_group1 : 1);
+  const int group = (h->btp && h->btp->nb > 1) ? h->rl_group : 1;
   int seg0 = cs;  // grouped schedule: first column (k-segment) the columns behind the chain's next one have not had yet
   if (two && t_pending) CKC(t_signal((cs + 1) % 3));  // polled by leaf cs: the index leaf j polls is (j - 2) mod 3 = (j + 1) mod 3
   for (int j = cs; j < ntc; ++j) {
@@ -1075,7 +1073,9 @@ static int factor_internal(mi_gp_handle* h, const double* theta, int what) {
   }
   const bool prof = h->prof_level >= 1;
   for (int attempt = 0;; ++attempt) {
+    const auto t_enq0 = std::chrono::steady_clock::now();
     if (int r = run_evaluation(h, what)) return r;
+    h->t_enqueue_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enq0).count();
     HCK(hipStreamSynchronize(h->stream), "stream sync");
     if ((int)h->out_host[3] != SIGNAL_TIMEOUT_INFO) break;
     if (int r = poll_timeout(h, attempt)) return r;
@@ -1126,13 +1126,13 @@ extern "C" int mi_gp_lml_parts(mi_gp_handle* h, double* logdet, double* quad) {
 }
 
 // out: [assemble_ms, chol_ms, reduce_ms, total_ms, gemm_ms, gemm_flops, n_gemm_launches,
-//       trtri_ms, lauum_ms, contract_ms, gemm_b_ms, gemm_b_flops, n_gemm_b_launches]
+//       trtri_ms, lauum_ms, contract_ms, gemm_b_ms, gemm_b_flops, n_gemm_b_launches, enqueue_ms (host, any profiling level)]
 extern "C" int mi_gp_timers(mi_gp_handle* h, double* out, int n) {
   if (!h || !out) return -1;
-  const double v[13] = {h->t_assemble_ms, h->t_chol_ms, h->t_reduce_ms, h->t_total_ms, h->t_gemm_ms, h->gemm_flops,
+  const double v[14] = {h->t_assemble_ms, h->t_chol_ms, h->t_reduce_ms, h->t_total_ms, h->t_gemm_ms, h->gemm_flops,
                         h->n_gemm, h->t_trtri_ms, h->t_lauum_ms, h->t_contract_ms, h->t_gemm_big_ms,
-                        h->gemm_big_flops, h->n_gemm_big};
-  for (int i = 0; i < n && i < 13; ++i) out[i] = v[i];
+                        h->gemm_big_flops, h->n_gemm_big, h->t_enqueue_ms};
+  for (int i = 0; i < n && i < 14; ++i) out[i] = v[i];
   return 0;
 }
 

@@ -207,10 +207,11 @@ MI_GP_API int mi_gp_get_option(mi_gp_handle* h, int what, int* value);
 
 /* profiling: level 0 none, 1 per-phase HIP events, 2 additionally per-GEMM-launch HIP events */
 MI_GP_API int mi_gp_set_profiling(mi_gp_handle* h, int level);
-/* out[0..12] = assemble_ms, cholesky_ms, reduce_ms, total_ms, gemm_ms (sum over launches),
+/* out[0..13] = assemble_ms, cholesky_ms, reduce_ms, total_ms, gemm_ms (sum over launches),
  *             gemm_flops (algorithmic), number of gemm launches, trtri_ms, lauum_ms, contract_ms,
  *             then the same three GEMM figures for the 128x128-tile kernel (gemm_f64_kernel_b) alone
- *             -- of the last evaluation (profiling level >= 1) */
+ *             -- of the last evaluation (profiling level >= 1);
+ *   out[13] = host time spent enqueueing the last single evaluation's launches, ms (measured at every profiling level) */
 MI_GP_API int mi_gp_timers(mi_gp_handle* h, double* out, int n);
 
 /* ---- block-level operations (also used by the multi-GPU driver and the parity tests) ---- */

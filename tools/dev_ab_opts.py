@@ -12,9 +12,10 @@ sets = args[3:]
 X, y = synth_problem(N, d, seed=0)
 gp = MiGP(X, y, kern, need_grad=grad)
 th = theta_sequence(d, 8, seed=0)
-DEFAULTS = {0: 1, 2: 0, 4: 1 << 20, 5: 0, 6: 0, 7: 1024, 8: 1 << 20, 9: 1, 14: 8, 16: 1, 18: 1536, 19: 1024, 20: 72, 21: 8, 24: 1, 26: 2, 32: 2048, 35: 32, 37: 24, 38: 8, 42: 1}
+DEFAULTS = {0: 1, 2: 0, 4: 1 << 20, 5: 0, 6: 0, 7: 1024, 8: 1 << 20, 9: 1, 14: 8, 16: 1, 18: 1536, 19: 1024, 20: 72, 21: 8, 24: 1, 26: 2, 32: 2048, 35: 32, 37: 24, 38: 8}
 res = {s: [] for s in sets}
 vals = {}
+enq = {}
 reps = 10 if N <= 8192 else 5
 f = (lambda t: gp.lml_grad(t)[0]) if grad else gp.lml
 for rnd in range(4):
@@ -29,6 +30,7 @@ for rnd in range(4):
         for i in range(reps):
             f(th[i % 8])
         res[s].append((time.perf_counter() - t0) / reps * 1e3)
+        enq[s] = gp.timers().get("enqueue_ms", 0.0)
 for s in sets:
     v = sorted(res[s])
-    print(f"N={N} {kern} {'lml+grad' if grad else 'lml'} [{s:>14s}] median {np.median(v):8.3f} ms  min {v[0]:8.3f}  max {v[-1]:8.3f}  value {vals[s]!r}", flush=True)
+    print(f"N={N} {kern} {'lml+grad' if grad else 'lml'} [{s:>14s}] median {np.median(v):8.3f} ms  min {v[0]:8.3f}  max {v[-1]:8.3f}  enqueue {enq[s]:6.3f} ms  value {vals[s]!r}", flush=True)

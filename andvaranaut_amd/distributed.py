@@ -310,7 +310,45 @@ class DistGP:
         if mode == "mesh" and self.collective and self.world > 2 and self.peer_groups is None:
             # peer_groups[o]: everybody but rank o (the ranks that all-gather a piece owner o scattered)
             self.peer_groups = [dist.new_group([r for r in range(self.world) if r != o]) for o in range(self.world)]
+        if mode == "mesh" and self.collective and self.world > 1 and dist.get_backend() == "nccl" and not getattr(self, "_mesh_checked", False):
+            self._mesh_selfcheck()
         self.exchange = mode
+
+    def _mesh_selfcheck(self):
+        """the RCCL path of the mesh exchange (grouped point-to-point sends, peer all-gather on per-owner subgroups)
+        never ran on hardware in rounds 1-6.  Before the first real panel travels that way, every owner in turn sends a small
+        pattern through exactly those primitives and through dist.broadcast; any rank that sees a difference raises (on
+        every rank: the verdict is all-reduced), so a transport problem shows up here and not as a wrong factor."""
+        W = self.world
+        npeer, cr = W - 1, 64
+        bad = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        with torch.cuda.device(self.dev):
+            for o in range(W):
+                ref = torch.zeros((cr * npeer, 128), dtype=torch.float64, device=self.dev)
+                got = torch.zeros_like(ref)
+                if o == self.rank:
+                    ref.copy_(torch.arange(ref.numel(), dtype=torch.float64, device=self.dev).reshape(ref.shape) * (o + 1) + 0.25)
+                    got.copy_(ref)
+                dist.broadcast(ref, src=o)
+                peers = [r for r in range(W) if r != o]
+                chunks = [got[g * cr: (g + 1) * cr] for g in range(npeer)]
+                if o == self.rank:
+                    for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, chunks[g], peers[g]) for g in range(npeer)]):
+                        w.wait()
+                else:
+                    g = peers.index(self.rank)
+                    for w in dist.batch_isend_irecv([dist.P2POp(dist.irecv, chunks[g], o)]):
+                        w.wait()
+                    if npeer > 1:
+                        dist.all_gather_into_tensor(got, chunks[g].clone(), group=self.peer_groups[o])
+                torch.cuda.synchronize(self.dev)
+                if not torch.equal(ref, got):
+                    bad += 1
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if int(bad.item()) != 0:
+            raise RuntimeError("DistGP.set_exchange('mesh'): the mesh exchange's transport self-check disagrees with dist.broadcast "
+                               "on at least one rank; staying with the broadcast exchange")
+        self._mesh_checked = True
 
     def _exchange(self, j):
         """Post the exchange of panel j under the current stream, one piece (tile column) at a time: the RCCL broadcasts

@@ -178,9 +178,11 @@ class Deadline:
 
 
 # ------------------------------------------------------------------------------------------------ sharded (config 4)
-def sharded_record(args, rank, world, dev, N, d, kernel, steps, warmup, grad=False):
+def sharded_record(args, rank, world, dev, N, d, kernel, steps, warmup, grad=False, exchange="bcast", lazy_sends=None,
+                   single_gpu_check=True):
     """ONE covariance sharded over all ranks (andvaranaut_amd/distributed.py): block-cyclic column panels, the owner
-    factors a panel and broadcasts it (RCCL), every rank updates the panels it owns.  Same theta on every rank."""
+    factors a panel and broadcasts it (RCCL), every rank updates the panels it owns.  Same theta on every rank.
+    ``exchange`` / ``lazy_sends``: DistGP.set_exchange / DistGP.lazy_sends (defaults: broadcast, the owner waits for its sends)."""
     import torch
     import torch.distributed as dist
 
@@ -188,6 +190,10 @@ def sharded_record(args, rank, world, dev, N, d, kernel, steps, warmup, grad=Fal
 
     X, y = synth_problem(N, d, seed=0)
     gp = DistGP(X, y, kernel, device=dev.index, panel_width_tiles=args.sharded_panel_tiles or None)
+    if exchange != "bcast":
+        gp.set_exchange(exchange)  # (collective: every rank makes the same call)
+    if lazy_sends is not None:
+        gp.lazy_sends = bool(lazy_sends)
     thetas = theta_sequence(d, warmup + steps, seed=0)
     for i in range(len(thetas)):  # config 4 is RBF at d=32: keep cond(K) in the benchmark regime
         thetas[i][-2] = 1e-4
@@ -217,9 +223,12 @@ def sharded_record(args, rank, world, dev, N, d, kernel, steps, warmup, grad=Fal
         "value": steps / elapsed, "unit": "evals/s", "ms_per_step": elapsed / steps * 1e3,
         "tflops_whole_eval": flops / (elapsed / steps) * 1e-12,
         "frac_of_fp64_peak_all_gpus": flops / (elapsed / steps) * 1e-12 / (FP64_PEAK_TFLOPS * world),
-        "parallelism": f"column-panel ({gp.pw} columns) block-cyclic x{world}, owner factors + RCCL broadcast, look-ahead 1",
+        "parallelism": f"column-panel ({gp.pw} columns) block-cyclic x{world}, owner factors + RCCL "
+                       f"{'broadcast' if exchange == 'bcast' else 'mesh exchange (scatter over the links + peer all-gather)'}, look-ahead 1",
+        "exchange": exchange, "lazy_sends": bool(lazy_sends) if lazy_sends is not None else "default",
         "bytes_broadcast_per_step": gp.bytes_broadcast / max(steps, 1),
-        "collectives": "rccl" if (dist.is_initialized() and dist.get_backend() == "nccl") else "none (single process)",
+        "collectives": ("rccl" if dist.get_backend() == "nccl" else f"{dist.get_backend()} (rehearsal: host-staged, not a measurement of the links)")
+                       if dist.is_initialized() else "none (single process)",
         "finite": bool(ok), "lml": float(vals[-1]),
     }
     gp_pwt = gp.pwt
@@ -228,7 +237,7 @@ def sharded_record(args, rank, world, dev, N, d, kernel, steps, warmup, grad=Fal
     torch.cuda.empty_cache()
     # parity of the sharded result on whatever hardware this runs on: rank 0 evaluates the same covariance once on the
     # single-GPU path (34 GB at N = 65536; a second or two) and the record carries the relative difference
-    if not grad and rank == 0:
+    if not grad and rank == 0 and single_gpu_check:
         try:
             from andvaranaut_amd import MiGP
 
@@ -243,9 +252,8 @@ def sharded_record(args, rank, world, dev, N, d, kernel, steps, warmup, grad=Fal
             rec["single_gpu_check"] = f"skipped: {type(e).__name__}: {e}"
     # the one-GPU rank emulation's prediction for this world size (tools/emulate_rank.py --curve), for the first hardware
     # run to be checked against: a model (measured per-rank compute and owner chain + bytes / link bandwidth), not a result
-    mfile = os.path.join(ROOT, "profiles", "r05_sharded_model.json")
-    if not os.path.exists(mfile):
-        mfile = os.path.join(ROOT, "profiles", "r04_sharded_model.json")
+    mfile = next((os.path.join(ROOT, "profiles", f"r0{r}_sharded_model.json") for r in (6, 5, 4)
+                  if os.path.exists(os.path.join(ROOT, "profiles", f"r0{r}_sharded_model.json"))), "")
     if not grad and os.path.exists(mfile):
         try:
             mj = json.load(open(mfile))
@@ -265,6 +273,54 @@ def sharded_record(args, rank, world, dev, N, d, kernel, steps, warmup, grad=Fal
         except Exception as e:  # noqa: BLE001
             rec["prediction_source"] = f"unreadable: {e}"
     return rec
+
+
+SHARDED_FORMS = (("bcast", False), ("bcast", True), ("mesh", False))  # (exchange, lazy owner sends); the first is the default
+
+
+def sharded_forms(args, rank, world, dev, N, d, kernel, steps, warmup, on_partial=None):
+    """The one multi-GPU run that may come measures EVERY exchange form, not just the default: broadcast with the
+    owner waiting for its sends (default), broadcast with lazy owner sends, and the mesh exchange -- back to back on the same
+    thetas, each under its own deadline, each beside its column of the one-GPU emulation's model.  The three LMLs must be
+    bit-equal (fixed world size and options: include/mi_gp.h); a form that fails or disagrees is reported, the others stand.
+    Returns the default form's record with a ``forms`` table; ``on_partial(rec)`` sees it after every form (the deadline's
+    handler prints what is there)."""
+    out = None
+    for exchange, lazy in SHARDED_FORMS:
+        name = f"{exchange}/{'lazy' if lazy else 'eager'}"
+
+        def expire(name=name):
+            if rank == 0 and out is not None:
+                out["forms"][name] = {"error": f"not finished after {args.sharded_timeout:.0f} s"}
+                if on_partial is not None:
+                    on_partial(out, final=True)
+            os._exit(3)
+
+        with Deadline(args.sharded_timeout, expire):
+            try:
+                rec = sharded_record(args, rank, world, dev, N, d, kernel, steps, warmup, exchange=exchange, lazy_sends=lazy,
+                                     single_gpu_check=out is None)
+            except Exception as e:  # noqa: BLE001 - one form's failure must not take the others (or the headline) down
+                rec = {"error": f"{type(e).__name__}: {e}"}
+        if out is None:
+            if "error" in rec:
+                return rec  # the default form itself failed: nothing to compare the others with
+            out = rec
+            out["forms"] = {}
+        pred = (out.get("predicted_ms_per_step_by_exchange_and_link") or {})
+        out["forms"][name] = ({"error": rec["error"]} if "error" in rec else
+                              {"ms_per_step": rec["ms_per_step"], "lml": rec["lml"], "finite": rec["finite"],
+                               "bytes_exchanged_per_step": rec["bytes_broadcast_per_step"],
+                               "bit_equal_to_default": rec["lml"] == out["lml"],
+                               "model_ms_per_step": {k: v for k, v in pred.items() if k.startswith(exchange + "@")} or None})
+        if on_partial is not None:
+            on_partial(out, final=False)
+    ok = [f for f in out["forms"].values() if "error" not in f]
+    out["forms_bit_equal"] = len(ok) == len(SHARDED_FORMS) and all(f["bit_equal_to_default"] for f in ok)
+    if ok:
+        best = min(out["forms"], key=lambda k: out["forms"][k].get("ms_per_step", float("inf")))
+        out["fastest_form"] = best
+    return out
 
 
 def main():
@@ -291,6 +347,9 @@ def main():
     ap.add_argument("--grad", action="store_true", help="with --sharded: time LML + gradient (sharded K^-1) instead of the LML")
     ap.add_argument("--grad-steps", type=int, default=5, help="LML + gradient evaluations timed after the LML region (0: skip)")
     ap.add_argument("--no-lookahead", action="store_true", help="disable the look-ahead stream everywhere (profiling aid)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: REHEARSAL of the multi-rank code path with every rank on GPU 0 and host-staged collectives "
+                         "(tests/test_gpu_distributed.py); its timings say nothing about the links")
     ap.add_argument("--chains-per-gpu", type=int, default=3,
                     help="extra record: this many handles evaluated side by side on every GPU (independent chains; 0/1: skip)")
     args = ap.parse_args()
@@ -307,6 +366,8 @@ def main():
     import torch
     import torch.distributed as dist
 
+    if args.backend == "gloo":
+        local_rank = 0  # rehearsal: every rank on the first GPU
     if torch.cuda.device_count() < (local_rank + 1):
         sys.exit(f"bench.py: rank {rank} needs GPU {local_rank}, this box has {torch.cuda.device_count()}")
     torch.cuda.set_device(local_rank)
@@ -318,20 +379,33 @@ def main():
         os.environ.setdefault("MASTER_PORT", str(_free_port()))
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-    dist.init_process_group(backend="nccl", device_id=dev)
+    if args.backend == "gloo":
+        dist.init_process_group(backend="gloo")
+    else:
+        dist.init_process_group(backend="nccl", device_id=dev)
     assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
     from andvaranaut_amd import MiGP
 
     if args.sharded:
-        rec = sharded_record(args, rank, world, dev, args.n or args.sharded_n, args.d or args.sharded_d,
-                             args.kernel or args.sharded_kernel, args.steps, args.warmup, grad=args.grad)
-        if rank == 0:
-            line = {"metric": rec["metric"], "value": rec["value"], "unit": "evals/s", "n_gpus": world, "rccl_ranks": dist.get_world_size(),
+        def as_line(rec):
+            return {"metric": rec["metric"], "value": rec["value"], "unit": "evals/s", "n_gpus": world, "rccl_ranks": dist.get_world_size(),
                     "steps": args.steps, "warmup": args.warmup, "ms_per_step": rec["ms_per_step"], "higher_is_better": True,
                     "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                     "config": {"workload": rec["workload"], "parallelism": rec["parallelism"]}, "sharded": rec}
-            print(json.dumps(line), flush=True)
+
+        sn, sd, sk = args.n or args.sharded_n, args.d or args.sharded_d, args.kernel or args.sharded_kernel
+        if world > 1 and not args.grad:
+            # every exchange form, back to back; the deadline's handler prints the line with the forms measured so far
+            rec = sharded_forms(args, rank, world, dev, sn, sd, sk, args.steps, args.warmup,
+                                on_partial=lambda r, final: print(json.dumps(as_line(r)), flush=True) if final else None)
+        else:
+            rec = sharded_record(args, rank, world, dev, sn, sd, sk, args.steps, args.warmup, grad=args.grad)
+        if rank == 0:
+            if "error" in rec:
+                print(json.dumps({"metric": "gp_lml_evals_per_s", "value": None, "n_gpus": world, "sharded": rec}), flush=True)
+            else:
+                print(json.dumps(as_line(rec)), flush=True)
         dist.barrier()
         dist.destroy_process_group()
         return
@@ -559,7 +633,25 @@ def main():
                 print(json.dumps(line), flush=True)
             os._exit(3)
 
-        with Deadline(args.sharded_timeout, expire):
+        if world > 1:
+            # the one hardware run that may come compares every exchange form (each under its own deadline inside sharded_forms);
+            # a form that hangs ends the process through its deadline AFTER the line -- replicas' numbers and the forms
+            # measured so far -- is out
+            def partial(r, final):
+                if rank == 0 and line is not None:
+                    line["sharded"] = r
+                    if final:
+                        print(json.dumps(line), flush=True)
+
+            try:
+                rec = sharded_forms(args, rank, world, dev, args.sharded_n, args.sharded_d, args.sharded_kernel,
+                                    args.sharded_steps, 1, on_partial=partial)
+            except Exception as e:  # noqa: BLE001
+                rec = {"error": f"{type(e).__name__}: {e}"}
+            if "error" in rec:
+                exit_code = 4
+        else:
+          with Deadline(args.sharded_timeout, expire):
             try:
                 rec = sharded_record(args, rank, world, dev, args.sharded_n, args.sharded_d, args.sharded_kernel,
                                      args.sharded_steps, 1)

@@ -87,8 +87,9 @@ def test_config5_n8192_lml_vs_oracle_then_nuts_on_device():
 
 
 def test_config4_sharded_driver_n65536_one_rank_equals_single_gpu_path():
-    """Config 4's shape through the sharded driver (64 column panels of 1024, panel-by-panel launches, no graph) against
-    the single-GPU path (super-panels + look-ahead + graph replay) on the same data: 1e-10."""
+    """Config 4's shape through the sharded driver (64 column panels of 1024, recursive in-panel updates, one panel-list launch
+    per step) against the single-GPU path (super-panels with look-ahead, extended panels, a column-by-column tail) on the same
+    data: 1e-10."""
     MiGP, _ = _mods()
     from andvaranaut_amd.distributed import DistGP
     from bench import synth_problem

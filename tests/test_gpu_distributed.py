@@ -186,6 +186,39 @@ def test_ranks_sharing_one_gpu_via_gloo(tmp_path, world):
     assert '"ok": true' in outs[0][0]
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_measures_every_exchange_form_end_to_end(world):
+    """at world > 1 bench.py's sharded record runs the broadcast with eager and with lazy owner sends and the
+    mesh exchange back to back, each under its own deadline, and compares their LMLs bit for bit.  Rehearsed here through the
+    bench's own code path with gloo ranks that share the one GPU (--backend gloo: host-staged collectives, so lazy sends fall
+    back to eager and the timings say nothing about links -- what is tested is that every form runs, agrees, and lands in the
+    line)."""
+    import json
+
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="4")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--sharded", "--backend", "gloo",
+                                       "--n", "3000", "--d", "4", "--kernel", "Matern52", "--steps", "2", "--warmup", "1",
+                                       "--sharded-panel-tiles", "2", "--sharded-timeout", "300"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=900) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-3000:]
+    line = json.loads([l for l in outs[0][0].splitlines() if l.startswith("{")][-1])
+    rec = line["sharded"]
+    assert line["n_gpus"] == world and line["scaling"] == "strong" and rec["finite"]
+    assert set(rec["forms"]) == {"bcast/eager", "bcast/lazy", "mesh/eager"}, rec["forms"]
+    assert all("error" not in f and f["finite"] and f["bit_equal_to_default"] for f in rec["forms"].values()), rec["forms"]
+    assert rec["forms_bit_equal"] is True and rec["fastest_form"] in rec["forms"]
+    assert rec["forms"]["mesh/eager"]["bytes_exchanged_per_step"] >= rec["forms"]["bcast/eager"]["bytes_exchanged_per_step"]
+    assert "gloo" in rec["collectives"]
+    # the sharded LML against the single-GPU path of the same covariance (rank 0 evaluates it once)
+    assert rec["rel_diff_vs_single_gpu_path"] <= SHARD_VS_SINGLE
+
+
 @pytest.mark.parametrize("world,pwt,N", [(3, 2, 3000), (4, 1, 1700), (2, 4, 4200), (8, 2, 9000)])
 def test_emulated_ranks_partition_the_factorisation(world, pwt, N):
     """Every rank of a `world`-rank job played in turn by one process (DistGP(emulate=...), the mode tools/emulate_rank.py

@@ -104,7 +104,7 @@ def test_random_case_many_components_and_dimensions(seed):
     theta[len(kerns) * d: len(kerns) * d + len(kerns)] = rng.uniform(0.5, 1.5, len(kerns))  # products of many kv stay O(1)
     cond = np.linalg.cond(orc.noisy_cov(X, kerns, ops, theta))
     tol = max(1e-10, 20.0 * cond * 2.2e-16)
-    gtol = max(1e-7, 200.0 * cond * 2.2e-16)
+    gtol = max(1e-7, 500.0 * cond * 2.2e-16)  # (the factor of the first sweep: see the comment there)
     gp = MiGP(X, y, kernel)
     val, g, gy, gx = gp.lml_grad_data(theta)
     ref, rg = orc.lml_grad(X, y, kerns, ops, theta)

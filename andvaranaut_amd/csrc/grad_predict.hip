@@ -112,8 +112,13 @@ __device__ __forceinline__ void base_kernel_val_der(int kid, double r2, double a
 // One 64x64 tile of the lower triangle per workgroup; thread (ty, tx) owns the 4x4 strided
 // micro-tile rows ty+16a, cols tx+16b.  part[blockIdx.x][p] receives the block's partial sums.
 // Parameter order p: ls(nk*d), kv(nk), alpha(nk), gv, jitter.
-template <int NK>
-__global__ __launch_bounds__(256) void grad_contract_kernel(KernSpec spec, const double* __restrict__ theta,
+// Occupancy (round 6): the kernel is bound by LDS / exp latency, not by issue -- at 176 VGPRs (two waves per SIMD) the N = 16384 pass
+// took 2.0 ms against ~0.6 ms of fp64 issue.  One and two components are built for three waves per SIMD (<= 168 VGPRs: the
+// weights' products with dk/dr2 are formed once, G = wc * dkv, and the five per-element arrays of the fold die before the
+// length-scale pass; RQ = false: no component is a rational quadratic, so d k / d alpha -- identically zero then -- is not carried);
+// N = 16384 LML + gradient 70.6 -> 69.9 ms on one box.  Same arithmetic, same bits.
+template <int NK, bool RQ>
+__global__ __launch_bounds__(256, NK == 1 ? 3 : (NK == 2 && !RQ) ? 2 : 1) void grad_contract_kernel(KernSpec spec, const double* __restrict__ theta,
                                                             const double* __restrict__ X, int n,
                                                             const double* __restrict__ W, long ldw,
                                                             const double* __restrict__ alpha_v,
@@ -173,7 +178,7 @@ __global__ __launch_bounds__(256) void grad_contract_kernel(KernSpec spec, const
     }
 
   // pass 1: per-component scaled squared distances r2[c] (direct form) -> value, derivative, fold
-  double kval[NK][4][4], dkv[NK][4][4], dal[NK][4][4];
+  double kval[NK][4][4], dkv[NK][4][4], dal[RQ ? NK : 1][4][4];
 #pragma unroll
   for (int c = 0; c < nk; ++c) {
     double r2[4][4];
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(256) void grad_contract_kernel(KernSpec spec, const
         base_kernel_val_der(kid, r2[a][b], alc, k, dk, da);
         kval[c][a][b] = kvc * k;
         dkv[c][a][b] = kvc * dk;
-        dal[c][a][b] = kvc * da;
+        if constexpr (RQ) dal[c][a][b] = kvc * da;
       }
   }
   // coefficient dK/dK_c of the left-to-right fold, times the weight
@@ -268,10 +273,10 @@ __global__ __launch_bounds__(256) void grad_contract_kernel(KernSpec spec, const
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         skv += wc[c][a][b] * kval[c][a][b];
-        sal += wc[c][a][b] * dal[c][a][b];
+        if constexpr (RQ) sal += wc[c][a][b] * dal[c][a][b];
       }
     skv = block_sum(skv);
-    sal = block_sum(sal);
+    if constexpr (RQ) sal = block_sum(sal);
     if (tid == 0) {
       out[nk * d + c] = skv / kv[c];
       out[nk * d + nk + c] = sal;
@@ -290,13 +295,21 @@ __global__ __launch_bounds__(256) void grad_contract_kernel(KernSpec spec, const
       out[nk * d + 2 * nk + 1] = sd;
     }
   }
-  // length scales: dK/dl_{c,m} = wc * kv dk/dr2 * (-2/l_m) * ((x_im - x_jm)/l_m)^2
+  // length scales: dK/dl_{c,m} = wc * kv dk/dr2 * (-2/l_m) * ((x_im - x_jm)/l_m)^2; G = wc * kv dk/dr2 once per element
 #pragma unroll
+  for (int c = 0; c < nk; ++c)
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) dkv[c][a][b] *= wc[c][a][b];
+#pragma unroll
+  // (one component with d <= GDCH: the scaled coordinates of pass 1 are still in LDS -- nothing to stage again)
+  const bool staged = NK == 1 && d <= GDCH;
   for (int c = 0; c < nk; ++c) {
     for (int m0 = 0; m0 < d; m0 += GDCH) {
       const int dc = min(GDCH, d - m0);
       __syncthreads();
-      {  // 256 % GDCH == 0: a thread always stages the same input dimension, one division per chunk
+      if (!staged) {  // 256 % GDCH == 0: a thread always stages the same input dimension, one division per chunk
         const int m = tid % GDCH;
         const double il = (m < dc) ? 1.0 / ls[c * d + m0 + m] : 0.0;
         for (int r = tid / GDCH; r < GT; r += 256 / GDCH) {
@@ -308,8 +321,8 @@ __global__ __launch_bounds__(256) void grad_contract_kernel(KernSpec spec, const
           Xi[r * GDLD + m] = vi;
           Xj[r * GDLD + m] = vj;
         }
+        __syncthreads();
       }
-      __syncthreads();
       // per-dimension sums: wave partials of all dimensions of the chunk go to LDS, ONE barrier, then thread m adds
       // its four (same order as a per-dimension block sum, two barriers per dimension less)
       for (int m = 0; m < dc; ++m) {
@@ -324,7 +337,7 @@ __global__ __launch_bounds__(256) void grad_contract_kernel(KernSpec spec, const
 #pragma unroll
           for (int b = 0; b < 4; ++b) {
             const double df = xi[a] - xj[b];
-            s += wc[c][a][b] * dkv[c][a][b] * (df * df);
+            s += dkv[c][a][b] * (df * df);
           }
         for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
         if ((tid & 63) == 0) red[4 * m + (tid >> 6)] = s;
@@ -611,6 +624,12 @@ int grad_contract_blocks(int n) {
   return nt * (nt + 1) / 2;
 }
 
+static bool has_ratquad(const KernSpec& spec) {
+  for (int c = 0; c < spec.nkern; ++c)
+    if (spec.kid[c] == KID_RATQUAD) return true;
+  return false;
+}
+
 hipError_t launch_grad_contract(const KernSpec& spec, const double* theta, const double* X, int n, const double* W,
                                 long ldw, const double* alpha, double* part, double* grad, hipStream_t stream, const Batch* bt) {
   const int nblk = grad_contract_blocks(n);
@@ -618,12 +637,28 @@ hipError_t launch_grad_contract(const KernSpec& spec, const double* theta, const
   const dim3 grid(nblk, 1, bt ? bt->nb : 1);
   const int sth = bt ? bt->stheta : 0;
   const long sW = bt ? bt->sW : 0, sal = bt ? bt->salpha : 0, sp = bt ? bt->spart : 0;
+  const bool rq = has_ratquad(spec);
   switch (spec.nkern) {
-    case 1: grad_contract_kernel<1><<<grid, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, 0, 0, 0, 0, sth, sW, sal, sp); break;
-    case 2: grad_contract_kernel<2><<<grid, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, 0, 0, 0, 0, sth, sW, sal, sp); break;
-    case 3: grad_contract_kernel<3><<<grid, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, 0, 0, 0, 0, sth, sW, sal, sp); break;
-    case 4: grad_contract_kernel<4><<<grid, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, 0, 0, 0, 0, sth, sW, sal, sp); break;
-    default: grad_contract_kernel<8><<<grid, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, 0, 0, 0, 0, sth, sW, sal, sp); break;
+    case 1:
+      if (rq) grad_contract_kernel<1, true><<<grid, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, 0, 0, 0, 0, sth, sW, sal, sp);
+      else grad_contract_kernel<1, false><<<grid, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, 0, 0, 0, 0, sth, sW, sal, sp);
+      break;
+    case 2:
+      if (rq) grad_contract_kernel<2, true><<<grid, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, 0, 0, 0, 0, sth, sW, sal, sp);
+      else grad_contract_kernel<2, false><<<grid, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, 0, 0, 0, 0, sth, sW, sal, sp);
+      break;
+    case 3:
+      if (rq) grad_contract_kernel<3, true><<<grid, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, 0, 0, 0, 0, sth, sW, sal, sp);
+      else grad_contract_kernel<3, false><<<grid, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, 0, 0, 0, 0, sth, sW, sal, sp);
+      break;
+    case 4:
+      if (rq) grad_contract_kernel<4, true><<<grid, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, 0, 0, 0, 0, sth, sW, sal, sp);
+      else grad_contract_kernel<4, false><<<grid, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, 0, 0, 0, 0, sth, sW, sal, sp);
+      break;
+    default:
+      if (rq) grad_contract_kernel<8, true><<<grid, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, 0, 0, 0, 0, sth, sW, sal, sp);
+      else grad_contract_kernel<8, false><<<grid, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, 0, 0, 0, 0, sth, sW, sal, sp);
+      break;
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
@@ -647,12 +682,28 @@ hipError_t launch_grad_contract_slab(const KernSpec& spec, const double* theta, 
   const int P = spec.nkern * spec.d + 2 * spec.nkern + 2;
   if (tw <= 0) return hipMemsetAsync(grad, 0, sizeof(double) * P, stream);
   const int nblk = (nt - tj0) * tw;
+  const bool rq = has_ratquad(spec);
   switch (spec.nkern) {
-    case 1: grad_contract_kernel<1><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, tw, tj0, row0, col0, 0, 0, 0, 0); break;
-    case 2: grad_contract_kernel<2><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, tw, tj0, row0, col0, 0, 0, 0, 0); break;
-    case 3: grad_contract_kernel<3><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, tw, tj0, row0, col0, 0, 0, 0, 0); break;
-    case 4: grad_contract_kernel<4><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, tw, tj0, row0, col0, 0, 0, 0, 0); break;
-    default: grad_contract_kernel<8><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, tw, tj0, row0, col0, 0, 0, 0, 0); break;
+    case 1:
+      if (rq) grad_contract_kernel<1, true><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, tw, tj0, row0, col0, 0, 0, 0, 0);
+      else grad_contract_kernel<1, false><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, tw, tj0, row0, col0, 0, 0, 0, 0);
+      break;
+    case 2:
+      if (rq) grad_contract_kernel<2, true><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, tw, tj0, row0, col0, 0, 0, 0, 0);
+      else grad_contract_kernel<2, false><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, tw, tj0, row0, col0, 0, 0, 0, 0);
+      break;
+    case 3:
+      if (rq) grad_contract_kernel<3, true><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, tw, tj0, row0, col0, 0, 0, 0, 0);
+      else grad_contract_kernel<3, false><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, tw, tj0, row0, col0, 0, 0, 0, 0);
+      break;
+    case 4:
+      if (rq) grad_contract_kernel<4, true><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, tw, tj0, row0, col0, 0, 0, 0, 0);
+      else grad_contract_kernel<4, false><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, tw, tj0, row0, col0, 0, 0, 0, 0);
+      break;
+    default:
+      if (rq) grad_contract_kernel<8, true><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, tw, tj0, row0, col0, 0, 0, 0, 0);
+      else grad_contract_kernel<8, false><<<nblk, 256, 0, stream>>>(spec, theta, X, n, W, ldw, alpha, part, tw, tj0, row0, col0, 0, 0, 0, 0);
+      break;
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;

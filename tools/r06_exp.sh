@@ -1,5 +1,6 @@
 #!/bin/bash
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd $ROOT
-python tools/ab_lib.py "2048 8 RBF" "4096 8 RBF" "6144 8 RBF" "8192 8 RBF" "16384 16 Matern52" "8192 8 RBF grad" -- andvaranaut_amd/libmi_gp.so tools/ab/lib_occ3_68.so tools/ab/lib_occ3_70.so > gpurun_out/r06_h_occ3.txt 2>&1
-grep median gpurun_out/r06_h_occ3.txt
+python -m pytest tests/test_gpu_grad_predict.py tests/test_gpu_batch.py tests/test_gpu_register_poison.py -m gpu -q -x > gpurun_out/r06_k_tests.txt 2>&1; echo "tests rc=$?"; tail -5 gpurun_out/r06_k_tests.txt
+python tools/ab_lib.py "4096 8 RBF grad" "8192 8 RBF grad" "16384 16 Matern52 grad" "8192 8 RBF+Matern32 grad" "8192 8 RatQuad grad" -- tools/ab/r05/andvaranaut_amd/libmi_gp.so andvaranaut_amd/libmi_gp.so tools/ab/lib_gc4b.so > gpurun_out/r06_k_gc.txt 2>&1
+grep median gpurun_out/r06_k_gc.txt

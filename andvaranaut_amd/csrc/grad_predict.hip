@@ -302,9 +302,9 @@ __global__ __launch_bounds__(256, NK == 1 ? 3 : (NK == 2 && !RQ) ? 2 : 1) void g
     for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int b = 0; b < 4; ++b) dkv[c][a][b] *= wc[c][a][b];
-#pragma unroll
   // (one component with d <= GDCH: the scaled coordinates of pass 1 are still in LDS -- nothing to stage again)
   const bool staged = NK == 1 && d <= GDCH;
+#pragma unroll
   for (int c = 0; c < nk; ++c) {
     for (int m0 = 0; m0 < d; m0 += GDCH) {
       const int dc = min(GDCH, d - m0);

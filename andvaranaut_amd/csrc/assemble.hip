@@ -84,8 +84,12 @@ __global__ __launch_bounds__(256, (KID_STATIC >= 0 && KID_STATIC != KID_RATQUAD)
     tj_end = cols_pad / AT;
   }
   if (chunk < chunk_lo || chunk >= chunk_hi) return;  // column-range launch (runs of TPW tiles = 512 columns; uniform per workgroup)
-  const int tj0 = chunk * TPW;
-  const int tj1 = min(tj0 + TPW, tj_end);
+  // gridDim.y > 1 (small problems, round 6): a run is split over that many workgroups -- N = 4096 is 288 runs, one per CU and 40 us
+  // each; which workgroup evaluates a tile does not enter its arithmetic
+  const int per = TPW / (int)gridDim.y;
+  const int tj0 = chunk * TPW + (int)blockIdx.y * per;
+  const int tj1 = min(tj0 + per, min(chunk * TPW + TPW, tj_end));
+  if (tj0 >= tj1) return;
   const int i0 = ti * AT;
   const int lane = tid & 63, wave = tid >> 6;
   const int n = lane & 15, q = lane >> 4;
@@ -356,7 +360,10 @@ hipError_t launch_assemble(const KernSpec& spec, const double* theta, const doub
   const int ds = sym ? 0 : diag_shift;
   const double* ed = sym ? extra_diag : nullptr;
   const bool resident = spec.nkern == 1 && spec.d <= DCH;
-  const dim3 grid(nblk, 1, bt ? bt->nb : 1);
+  // few runs (N <= 6144 for one problem): split each over 2 / 4 / 8 workgroups so that every CU has several to overlap
+  const long nwg = (long)nblk * (bt ? bt->nb : 1);
+  const int split = one_per_cu ? 1 : nwg >= 2048 ? 1 : nwg >= 1024 ? 2 : nwg >= 512 ? 4 : 8;
+  const dim3 grid(nblk, split, bt ? bt->nb : 1);
   const long sK = bt ? bt->sK : 0;
   const int sth = bt ? bt->stheta : 0;
   // one_per_cu: unused dynamic LDS pushes the request over half a CU, so that the panel chain's leaf (which needs a CU to

@@ -29,7 +29,6 @@ from .transform import _none_conrev, wgp
 MAX_POLLING_HANDLES = 6
 
 
-
 def save_object(obj, fname):
     """core.py:21-23: whole-object checkpoint with cloudpickle (a GPMCMC drops its device handle, see __getstate__)."""
     import cloudpickle

@@ -16,7 +16,7 @@ dev = torch.device("cuda:0")
 torch.manual_seed(0)
 ld = 16384 + 16
 A = torch.randn(16384 + 128, ld, dtype=torch.float64, device=dev) * 0.01
-shapes = [(3072, 2944, 128), (3072, 2944, 256), (3072, 2944, 512), (8192, 7168, 1024), (6144, 5120, 512), (4096, 3072, 512), (4096, 3072, 128), (15360, 1024, 1024), (15360, 896, 1024), (15360, 512, 512), (15360, 256, 256), (15360, 128, 128),
+shapes = [(3072, 2944, 32), (3072, 2944, 64), (3072, 2944, 128), (3072, 2944, 256), (3072, 2944, 512), (4096, 3968, 128), (2048, 1920, 128), (8192, 7168, 1024), (6144, 5120, 512), (4096, 3072, 512), (4096, 3072, 128), (15360, 1024, 1024), (15360, 896, 1024), (15360, 512, 512), (15360, 256, 256), (15360, 128, 128),
           (8192, 1024, 1024), (8192, 512, 512), (8192, 128, 128), (4096, 1024, 1024), (4096, 512, 512), (4096, 128, 128),
           (2048, 512, 512), (2048, 128, 128)]
 out = []

@@ -283,6 +283,39 @@ class GPMCMC(ConsumersMixin):
             print(f"R^2 for y is: {out['r2']:0.5f}")
         return out
 
+    def y_dist(self, mode="hist_kde", nsamps=None, return_data=False, surrogate=True, seed=None):
+        """Uncertainty propagation through the surrogate (gpmcmc.py:140-151; tutorial.ipynb cell 34): a Latin-hypercube sample of the
+        input priors is pushed through ``predict`` (one device sweep via U = L^-T for large ``nsamps``).  The density plots of
+        LHC.__y_dist (lhc.py:100-110) are outside this backend's scope: ``mode`` is validated as there and otherwise ignored.
+        ``surrogate=False``: the underlying data set.  ``return_data=True`` returns (x, y) as the reference does."""
+        modes = ["hist", "kde", "ecdf", "hist_kde"]
+        if mode not in modes:
+            raise Exception(f"Error: selected mode must be one of {modes}")
+        if not isinstance(surrogate, bool):
+            raise Exception("Error: surrogate argument must be of type bool")
+        if not surrogate:
+            return (self.x, self.y) if return_data else None
+        xsamps = latin_sample(self.priors, nsamps, seed)
+        ypreds = self.predict(xsamps)
+        if return_data:
+            return xsamps, ypreds
+
+    def relative_importances(self, logscale=False):
+        """Inverse length scales of the fitted model (gpmcmc.py:1030-1037 draws them as a bar chart; here the values are returned)."""
+        if self.hypers is None:
+            raise Exception("Error: fit the GP before asking for relative importances")
+        ri = 1.0 / np.asarray(self.hypers["l"], dtype=np.float64)
+        return np.log(ri) if logscale else ri
+
+    def test_plots(self, revert=True, yplots=True, xplots=True, logscale=False, iwgp=False, cwgp=False, method="none",
+                   errorbars=True, saveyfig=None, xlab=None, ylab=None, returndat=False):
+        """Signature of the reference's ``test_plots`` (gpmcmc.py:933-1026) for drop-in callers: the train / test fit and the
+        four printed figures are ``test_stats``; the matplotlib figures themselves are outside this backend's scope, so the
+        plotting arguments are accepted and ignored.  ``returndat=True`` returns (xtest, ytest, ypred, yvars) as there."""
+        st_ = self.test_stats(revert=revert, iwgp=iwgp, cwgp=cwgp, method=method)
+        if returndat:
+            return st_["xtest"], st_["ytest"], st_["ypred"], st_["yvars"]
+
     def change_model(self, kernel=None, noise=None, mean=None):
         """gpmcmc.py:472-519: kernel string grammar, noise flag, mean function; scrubs the fitted model."""
         kernel = self.kernel if kernel is None else kernel

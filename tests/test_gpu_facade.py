@@ -75,6 +75,8 @@ def test_holdout_rmse_drawn_the_way_the_tutorial_draws_its_test_points():
             st_ = g.test_stats(revert=True)
             rmses.append(st_["rmse"])
             r2s.append(st_["r2"])
+        xt_, yt_, yp_, yv_ = g.test_plots(returndat=True)  # (the reference's entry point: same numbers, no figures)
+        assert np.isclose(np.sqrt(np.mean((yp_ - yt_) ** 2)), rmses[-1]) and xt_.shape == (10, 2) and np.all(yv_ > -1e-12)
     print("holdout RMSE per (sample, split):", ["%.2e" % r for r in rmses])
     assert min(rmses) <= 1.44e-4 <= max(rmses) and np.median(rmses) <= 3.6e-4 and min(r2s) > 0.99995, (rmses, r2s)
 
@@ -87,6 +89,14 @@ def test_matern_noise_fit_train_test_and_change_model():
     yt = np.array([fun(r) for r in xt])
     rmse = np.sqrt(np.mean((g.predict(xt) - yt) ** 2))
     assert rmse < 5e-3, rmse  # notebook: 1.1e-4 (tutorial.ipynb:678)
+    # tutorial.ipynb cell 34: propagate the input uncertainty through the surrogate (the density plot is out of scope)
+    xs, ys = g.y_dist(mode="hist_kde", nsamps=400, return_data=True, surrogate=True, seed=3)
+    assert xs.shape == (400, 2) and ys.shape == (400, 1) and np.all(np.isfinite(ys))
+    ytrue = np.array([fun(r) for r in xs])
+    assert np.sqrt(np.mean((ys - ytrue) ** 2)) < 5e-3
+    assert g.relative_importances().shape == (2,) and np.allclose(g.relative_importances(logscale=True), -np.log(g.hypers["l"]))
+    with pytest.raises(Exception, match="selected mode"):
+        g.y_dist(mode="violin", nsamps=10)
     g.change_model(kernel="RBF+Matern32", noise=True)
     assert g.hypers is None and g.gp is None
     g.fit(method="map", truncate=True)

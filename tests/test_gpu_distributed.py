@@ -219,6 +219,32 @@ def test_bench_measures_every_exchange_form_end_to_end(world):
     assert rec["rel_diff_vs_single_gpu_path"] <= SHARD_VS_SINGLE
 
 
+def test_bench_default_line_carries_the_exchange_forms_at_world_2():
+    """The DEFAULT bench line (replicas headline + sharded sub-record, what the driver's scaling run calls) at world 2, rehearsed with
+    gloo ranks on one GPU and small sizes: the headline survives, the sub-record holds the three forms and their bit comparison."""
+    import json
+
+    world, port = 2, _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="4")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--backend", "gloo",
+                                       "--n", "2500", "--d", "4", "--steps", "3", "--warmup", "1", "--grad-steps", "1", "--chains-per-gpu", "0",
+                                       "--roofline-steps", "1", "--sharded-n", "3000", "--sharded-d", "4", "--sharded-kernel", "Matern52",
+                                       "--sharded-steps", "2", "--sharded-panel-tiles", "2", "--sharded-timeout", "300"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=900) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-3000:]
+    line = json.loads([l for l in outs[0][0].splitlines() if l.startswith("{")][-1])
+    assert line["metric"] == "gp_lml_evals_per_s" and line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["roofline"]["unit"] == "TFLOP/s" and line["lml_grad"]["ms_per_eval"] > 0 and "cpu_baseline" not in line
+    rec = line["sharded"]
+    assert set(rec["forms"]) == {"bcast/eager", "bcast/lazy", "mesh/eager"} and rec["forms_bit_equal"] is True, rec.get("forms")
+    assert rec["scaling"] == "strong" and rec["n_gpus"] == 2 and rec["rel_diff_vs_single_gpu_path"] <= SHARD_VS_SINGLE
+
+
 @pytest.mark.parametrize("world,pwt,N", [(3, 2, 3000), (4, 1, 1700), (2, 4, 4200), (8, 2, 9000)])
 def test_emulated_ranks_partition_the_factorisation(world, pwt, N):
     """Every rank of a `world`-rank job played in turn by one process (DistGP(emulate=...), the mode tools/emulate_rank.py

@@ -50,6 +50,7 @@ struct mi_gp_handle {
   int u_leaf_done, u_node_done[12]; // tile columns whose leaf block of U is done / full nodes done per level
   int thin_max_wg;                  // option 32: in-panel updates of at most this many 16-row x 128-column slices (k = 128, at most
                                     // THIN_MAX_COLS tile columns) run on the thin kernel (thin_f64.hip); 0: never
+  int start_on_panel;               // option 45: see enqueue_factor (default 1; scheduling only)
   int rl_group;                     // option 38: column mode of a BATCH applies the main stream's k = 128 updates to the far columns in
                                     // k-segmented launches of this many columns (same bits, the trailing matrices read and written once per group)
   int rl_cols;                      // option 37: the last rl_cols tile columns are factored COLUMN BY COLUMN (cholesky(): column mode); 0: never
@@ -71,6 +72,8 @@ struct mi_gp_handle {
   int asm_split;       // option 24: assemble the first super-panel's columns first, the rest beside its factorisation (default 1)
   hipEvent_t asm_ev;   // recorded behind the first part; the panel stream starts there
   bool asm_ev_valid;
+  bool asm_on_panel;   // this evaluation's set_yrows + assembly were queued on the PANEL stream (column mode from the start on two
+                       // streams: the first leaf follows them in stream order, no cross-stream edge in front of the chain)
   int single_below;    // option 21: trailing tile columns at or below which a two-stream factorisation continues on one stream (0: never)
   int merge_min_tiles; // option 20: trailing sizes (tile columns) from which the next super-panel's update rides at the head of the
                        // trailing update's enumeration instead of in launches of its own (0: never)
@@ -248,6 +251,8 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   h->demoted = false;
   h->thin_max_wg = 2048;
   h->rl_cols = 24;
+  h->start_on_panel = 1;
+  h->asm_on_panel = false;
   h->rl_group = 8;
   h->ext_rows = 32;
   h->done_col = h->done_slot = -1;
@@ -350,6 +355,7 @@ extern "C" int mi_gp_set_option(mi_gp_handle* h, int what, int value) {
   else if (what == 35) h->ext_rows = value < 0 ? 0 : value;
   else if (what == 37) h->rl_cols = value < 0 ? 0 : value;
   else if (what == 38) h->rl_group = value < 1 ? 1 : value > 8 ? 8 : value;
+  else if (what == 45) h->start_on_panel = value ? 1 : 0;
   else if (what == 9) h->tail_small = value ? 1 : 0;
   else {
     snprintf(h->err, sizeof(h->err), "mi_gp_set_option: unknown option %d", what);
@@ -384,6 +390,7 @@ extern "C" int mi_gp_get_option(mi_gp_handle* h, int what, int* value) {
     case 35: *value = h->ext_rows; break;
     case 37: *value = h->rl_cols; break;
     case 38: *value = h->rl_group; break;
+    case 45: *value = h->start_on_panel; break;
     case 40: *value = h->demoted ? 1 : 0; break;
     default:
       snprintf(h->err, sizeof(h->err), "mi_gp_get_option: unknown option %d", what);
@@ -752,10 +759,14 @@ static hipError_t cholesky_enqueue(mi_gp_handle* h, double* A, long lda, int ntr
   // the panel stream starts after what is queued on the main stream (assembly) -- or, when the assembly was split, after its
   // first part (the first super-panel's columns); the first main-stream update sits behind the second part anyway
   if (P != T) {
-    if (h->asm_ev_valid && P == h->pstream) CKE(hipStreamWaitEvent(P, h->asm_ev, 0));
+    if (h->asm_on_panel && P == h->pstream) {}  // (the assembly is in front of the chain on this very stream)
+    else if (h->asm_ev_valid && P == h->pstream) CKE(hipStreamWaitEvent(P, h->asm_ev, 0));
     else CKE(hand_off(h, T, P));
+  } else if (h->asm_on_panel) {
+    CKE(hand_off(h, h->pstream, T));  // (cannot happen: enqueue_factor decides by the rule below; kept for safety)
   }
   h->asm_ev_valid = false;
+  h->asm_on_panel = false;
   const int wcap = (la_single && ntc <= NARROW_PANELS_MAX_TILES) ? 4 : 0;
   int w = pick_w(h, ntc, wcap);
   // EXTENDED super-panels (round 5, option 35): in the chain-bound part of a factorisation the panel's own in-panel updates
@@ -979,9 +990,20 @@ static hipError_t cholesky_enqueue(mi_gp_handle* h, double* A, long lda, int ntr
 // Kernels of one evaluation: assembly, factorisation of the augmented trapezoid [[K],[y^T]] (L ends
 // up in K_dev, beta = L^-1 y in row np), reduction.
 static int enqueue_factor(mi_gp_handle* h, int noise_form, bool prof) {
-  if (prof) (void)hipEventRecord(h->ev[0], h->stream);
+  // Problems that run in column mode from the start on two streams (8 .. rl_cols tile columns; round 6): the evaluation's first two
+  // kernels go to the PANEL stream, so that the first leaf follows the assembly in stream order instead of behind a cross-stream
+  // edge (~10 us of a 0.3 ms evaluation at N = 1024).  The main stream's first launch waits for a leaf's start signal anyway,
+  // and every API call ends with both streams drained.  Same launches: scheduling only.  (The rule is cholesky_enqueue's.)
+  {
+    const int nb_ = h->btp ? h->btp->nb : 1;
+    const bool la_ = h->lookahead == 2 || (h->lookahead == 1 && h->ntc >= lookahead_min_tiles(h, h->ntc)) ||
+                     (h->lookahead == 1 && nb_ >= 2 && h->ntc >= (nb_ >= 8 ? 20 : 24));
+    h->asm_on_panel = la_ && h->rl_cols > 0 && h->ntc <= h->rl_cols && h->start_on_panel;
+  }
+  const hipStream_t s0 = h->asm_on_panel ? h->pstream : h->stream;
+  if (prof) (void)hipEventRecord(h->ev[0], s0);
   // first kernel of the evaluation: y rows, the bad-pivot word, and theta from the pinned host buffer to theta_dev
-  HCK(launch_set_yrows(h->buf.K_dev, h->buf.lda, h->np, h->np, h->buf.y_dev, h->n, h->stream, h->info_dev, h->theta_host,
+  HCK(launch_set_yrows(h->buf.K_dev, h->buf.lda, h->np, h->np, h->buf.y_dev, h->n, s0, h->info_dev, h->theta_host,
                        h->theta_dev, h->ntheta, h->btp), "set_yrows");
   // Two-stream evaluations of one problem: the first super-panel's factorisation needs only the first 1024 columns of K and
   // runs on an otherwise idle chip (0.73 ms at N = 16384).  Those columns (the first two 512-column runs of every tile row)
@@ -1002,9 +1024,9 @@ static int enqueue_factor(mi_gp_handle* h, int noise_form, bool prof) {
                         h->np, 1, noise_form, h->stream, 0, h->diag_dev, h->btp, c0, 2147483647, 1), "assemble (rest)");
   } else {
     HCK(launch_assemble(h->spec, h->theta_dev, h->buf.X_dev, h->n, h->buf.X_dev, h->n, h->buf.K_dev, h->buf.lda, h->np,
-                        h->np, 1, noise_form, h->stream, 0, h->diag_dev, h->btp), "assemble");
+                        h->np, 1, noise_form, s0, 0, h->diag_dev, h->btp), "assemble");
   }
-  if (prof) (void)hipEventRecord(h->ev[1], h->stream);
+  if (prof) (void)hipEventRecord(h->ev[1], s0);
   HCK(cholesky(h, h->buf.K_dev, h->buf.lda, h->ntc + 1, h->ntc), "cholesky");
   if (prof) (void)hipEventRecord(h->ev[2], h->stream);
   // the scalars go straight to the pinned host buffer (device-visible): no download launch behind the reduction

@@ -224,13 +224,13 @@ def test_column_mode_and_extended_panels_return_the_same_bits_on_every_schedule(
     v0, g0 = gp.lml_grad(theta)
     ref = orc.lml(X, y, ["Matern52"], [], theta)
     assert abs(v0 - ref) <= 1e-10 * abs(ref)
-    for opts in ([(0, 0)], [(0, 2)], [(26, 0)], [(26, 1)], [(26, 0), (0, 2)], [(21, 16)], [(30, 0)]):
+    for opts in ([(0, 0)], [(0, 2)], [(26, 0)], [(26, 1)], [(26, 0), (0, 2)], [(21, 16)], [(30, 0)], [(45, 0)], [(45, 0), (26, 0)]):
         for k, v in opts:
             gp.set_option(k, v)
         v1, g1 = gp.lml_grad(theta)
         assert v1 == v0 and np.array_equal(g1, g0), opts
         assert gp.lml(theta) == v0, opts
-        for k, v in {0: 1, 26: 2, 21: 8, 30: 16}.items():
+        for k, v in {0: 1, 26: 2, 21: 8, 30: 16, 45: 1}.items():
             gp.set_option(k, v)
     gp.close()
 

@@ -24,6 +24,10 @@ BUDGET = {
     "syrk_thin_kernelILi128E": (128, False),
     "syrk_thin_kernelILi256E": (192, False),
     "trsm_strip128_kernelILi1E": (224, False),        # (210 as tuned: two waves per SIMD)
+    # round 6: the contraction is bound by LDS / exp latency -- one component without a rational quadratic runs three waves per SIMD
+    # (140 VGPRs; 176 = two waves cost 0.7 ms of the N = 16384 LML + gradient), two components two waves (230)
+    "grad_contract_kernelILi1ELb0E": (168, False),
+    "grad_contract_kernelILi2ELb0E": (256, False),
 }
 
 
@@ -40,7 +44,7 @@ def _metadata(obj):
 
 
 def test_tuned_kernels_keep_their_register_budgets():
-    objs = [os.path.join(CSRC, f) for f in ("gemm_f64.o", "thin_f64.o", "leaf_f64.o")]
+    objs = [os.path.join(CSRC, f) for f in ("gemm_f64.o", "thin_f64.o", "leaf_f64.o", "grad_predict.o")]
     if not all(os.path.exists(o) for o in objs) or not os.path.exists(os.path.join(chk.LLVM, "llvm-readelf")):
         pytest.skip("csrc/*.o or llvm-readelf missing (run __graft_entry__.build() first)")
     text = "".join(_metadata(o) for o in objs)

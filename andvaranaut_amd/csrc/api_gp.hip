@@ -612,8 +612,10 @@ constexpr int LOOKAHEAD_MIN_TILES = 20;  // round 4: with the single-stream tail
 
 // ... and from COLUMN_MODE_MIN_TILES on when the whole problem runs in column mode (round 5: three launches per column on the
 // panel stream, the rest on the main stream: one stream vs two at N = 1024 0.348 vs 0.336 ms, 1536 0.512 vs 0.475, 2048 0.665 vs
-// 0.619; in panel mode two streams still lose there: N = 2048 0.665 vs 0.699)
-constexpr int COLUMN_MODE_MIN_TILES = 8;
+// 0.619; in panel mode two streams still lose there: N = 2048 0.665 vs 0.699).  Round 6: with the evaluation STARTING on the
+// panel stream (option 45: no hand-off ahead of the first leaf) two streams win from 4 tile columns on (one stream vs two:
+// N = 384 0.124 vs 0.124 ms, 512 0.168 vs 0.158, 640 0.211 vs 0.195, 768 0.258 vs 0.236, 896 0.305 vs 0.273); it was 8.
+constexpr int COLUMN_MODE_MIN_TILES = 4;
 static int lookahead_min_tiles(const mi_gp_handle* h, int ntc);
 
 static hipError_t u_levels(mi_gp_handle* h, int final_cols, int max_s);

@@ -575,13 +575,13 @@ class GPMCMC(ConsumersMixin):
         def run_lane(dev, cs, h_existing, shared, nlanes=1):
             try:
                 h = h_existing or MiGP(xin, yin, self.kernel, device=dev)
-                # Lanes that SHARE a GPU give up the look-ahead stream up to 64 tile columns (two streams start at 8 since
-                # column mode): the other lanes fill the idle CUs anyway and a hand-off between two streams costs ~5-10 us
+                # Lanes that SHARE a GPU give up the look-ahead stream up to 64 tile columns (two streams start at 4 since
+                # round 6): the other lanes fill the idle CUs anyway and a hand-off between two streams costs ~5-10 us
                 # (three handles, LML + gradient: N = 6144 176 -> 202 evaluations/s, N = 8192 94 -> 97; from 72 tile columns on
                 # there is nothing in it).  The super-panel width is pinned to the one the two-stream driver would pick, so
                 # the arithmetic -- and every draw -- is bit-identical to the default schedule.
                 ntc = (len(yin) + 127) // 128
-                pinned = shared and 8 <= ntc <= 64
+                pinned = shared and 4 <= ntc <= 64
                 before26 = None
                 if shared and not pinned and nlanes > MAX_POLLING_HANDLES:
                     # Two-stream lanes enqueue in-kernel polls ahead of the writes they wait for (include/mi_gp.h, option 26):

@@ -137,8 +137,8 @@ MI_GP_API int mi_gp_predict_grad(mi_gp_handle* h, const double* Xnew_dev, int m,
 
 /* tuning knobs (benchmarks / A-B tests), ALL per handle -- nothing here is process-wide:
  *   0  look-ahead: factor the next super-panel on a second stream while the trailing update runs; 0 never, 1 by size
- *      (default: from 20 tile columns = N > 2432 on, where the overlap beats the cross-stream hand-offs -- and from 8 tile
- *      columns on for problems that run in column mode from the start, option 37), 2 always
+ *      (default: from 20 tile columns = N > 2432 on, where the overlap beats the cross-stream hand-offs -- and from 4 tile
+ *      columns = N > 384 on for problems that run in column mode from the start, options 37 and 45), 2 always
  *   2  super-panel width in 128-column tiles (default 0 = by trailing size, options 4-6)
  *   4-6  trailing sizes (tile columns) above which the super-panel is 16 / 8 / 4 tiles wide (below the last: 2);
  *        defaults: never 16, else 8; with look-ahead active, problems of up to 64 tile columns use at most 4
@@ -189,7 +189,7 @@ MI_GP_API int mi_gp_predict_grad(mi_gp_handle* h, const double* Xnew_dev, int m,
  *   37 column mode: the last this-many tile columns (default 24; 0: never) are factored column by column -- leaf, strip and one
  *      k = 256 thin update of the next column on the panel stream; older columns reach a column through k = 128 updates on the
  *      main stream, a column behind the chain.  Problems of up to that many tile columns run in it from the start, on two
- *      streams from 8 tile columns on.  Regroups sums (agreement to rounding); a rule of the shape alone: one stream, two
+ *      streams from 4 tile columns on (round 6; it was 8 before option 45).  Regroups sums (agreement to rounding); a rule of the shape alone: one stream, two
  *      streams and a batch return the same bits.  N = 2048 0.665 -> 0.619 ms, 3072 0.981 -> 0.920, 4096 1.471 -> 1.443.
  *   38 column mode of a BATCH: the main stream applies its k = 128 updates to the columns behind the chain's next one in
  *      k-segmented launches of this many columns (default 8; 1: one launch per column as for a single evaluation).  The tile

@@ -262,9 +262,9 @@ def test_round5_arithmetic_options_agree_to_rounding_and_off_is_the_round4_chain
     gp.close()
 
 
-@pytest.mark.parametrize("ntc,ragged", [(7, 0), (8, -37), (9, 0), (19, -1), (20, 0), (23, -100), (24, 0), (25, -3), (28, 0), (29, -64), (33, 0)])
+@pytest.mark.parametrize("ntc,ragged", [(3, 0), (4, -20), (5, 0), (7, 0), (8, -37), (9, 0), (19, -1), (20, 0), (23, -100), (24, 0), (25, -3), (28, 0), (29, -64), (33, 0)])
 def test_tile_column_counts_around_the_round5_thresholds(ntc, ragged):
-    """One stream below 8 tile columns, column mode from the start up to 24, an entry into it behind one or more super-panels
+    """One stream below 4 tile columns (8 until round 6), column mode from the start up to 24, an entry into it behind one or more super-panels
     above, extended panels from 20: every boundary of those rules (and ragged last tiles) against the oracle, LML and gradient,
     and a batch of three against the single entry point."""
     MiGP, orc = _mods()

@@ -69,9 +69,6 @@ struct mi_gp_handle {
   int band_rows;    // band height of the band-column-major tile order of uniform-k trapezoid launches
   int split_tiles;  // option 18: tiles of a bulk update that run one workgroup per CU beside the chain; the rest two per CU (0: no split)
   int split_min_rest;  // option 19: ... only when at least this many tiles remain for the second part
-  int asm_split;       // option 24: assemble the first super-panel's columns first, the rest beside its factorisation (default 1)
-  hipEvent_t asm_ev;   // recorded behind the first part; the panel stream starts there
-  bool asm_ev_valid;
   bool asm_on_panel;   // this evaluation's set_yrows + assembly were queued on the PANEL stream (column mode from the start on two
                        // streams: the first leaf follows them in stream order, no cross-stream edge in front of the chain)
   int single_below;    // option 21: trailing tile columns at or below which a two-stream factorisation continues on one stream (0: never)
@@ -151,7 +148,6 @@ static void release_handle(mi_gp_handle* h) {
   for (int i = 0; i < 8; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
   for (auto& ev : h->gemm_ev) (void)hipEventDestroy(ev);
   for (auto& ev : h->ev_pool) (void)hipEventDestroy(ev);
-  if (h->asm_ev) (void)hipEventDestroy(h->asm_ev);
   if (h->pstream) (void)hipStreamDestroy(h->pstream);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -234,8 +230,6 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   h->split_min_rest = 1024;
   h->merge_min_tiles = 72;
   h->single_below = 8;  // (16 with event hand-offs; with option 26: N = 4096 1.983 -> 1.958 ms, 8192 5.50 -> 5.49, 16384 26.84 -> 26.73)
-  h->asm_split = 1;
-  h->asm_ev_valid = false;
   h->use_smo = 2;
   {
     // hipStreamWriteValue32 / hipStreamWaitValue32 need driver support: without it every two-stream evaluation would fail,
@@ -284,8 +278,6 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   if (e == hipSuccess) e = hipHostMalloc(&h->out_host, sizeof(double) * 16);
   if (e == hipSuccess) e = hipHostMalloc(&h->theta_host, sizeof(double) * h->ntheta);
   for (int i = 0; i < 8 && e == hipSuccess; ++i) e = hipEventCreate(&h->ev[i]);
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->asm_ev, hipEventDisableTiming);
-  if (e == hipSuccess) e = assemble_enable_lds();
   if (e == hipSuccess) e = gemm_f64_enable_lds();
   if (e == hipSuccess) e = leaf_enable_lds();
   if (e == hipSuccess && h->use_smo >= 2) e = probe_dispatch(h);
@@ -335,7 +327,6 @@ extern "C" int mi_gp_set_option(mi_gp_handle* h, int what, int value) {
   else if (what == 19) h->split_min_rest = value;
   else if (what == 20) h->merge_min_tiles = value;
   else if (what == 21) h->single_below = value;
-  else if (what == 24) h->asm_split = value ? 1 : 0;
   else if (what == 26) {
     h->use_smo = !h->smo_supported ? 0 : value < 0 ? 0 : value > 2 ? 2 : value;
     if (h->use_smo != 0) h->demoted = false;  // (the caller asks for polls again: the next time-out demotes again)
@@ -380,7 +371,6 @@ extern "C" int mi_gp_get_option(mi_gp_handle* h, int what, int* value) {
     case 19: *value = h->split_min_rest; break;
     case 20: *value = h->merge_min_tiles; break;
     case 21: *value = h->single_below; break;
-    case 24: *value = h->asm_split; break;
     case 26: *value = h->use_smo; break;
     case 27: *value = h->poll_limit_log2; break;
     case 28: *value = h->test_drop_signal; break;
@@ -758,16 +748,13 @@ static hipError_t cholesky_enqueue(mi_gp_handle* h, double* A, long lda, int ntr
     CKE(hipMemset(h->sig_dev, 0, sizeof(unsigned) * SIG_SLOTS));
     h->sig_epoch = 1;
   }
-  // the panel stream starts after what is queued on the main stream (assembly) -- or, when the assembly was split, after its
-  // first part (the first super-panel's columns); the first main-stream update sits behind the second part anyway
+  // the panel stream starts after what is queued on the main stream (assembly)
   if (P != T) {
     if (h->asm_on_panel && P == h->pstream) {}  // (the assembly is in front of the chain on this very stream)
-    else if (h->asm_ev_valid && P == h->pstream) CKE(hipStreamWaitEvent(P, h->asm_ev, 0));
     else CKE(hand_off(h, T, P));
   } else if (h->asm_on_panel) {
     CKE(hand_off(h, h->pstream, T));  // (cannot happen: enqueue_factor decides by the rule below; kept for safety)
   }
-  h->asm_ev_valid = false;
   h->asm_on_panel = false;
   const int wcap = (la_single && ntc <= NARROW_PANELS_MAX_TILES) ? 4 : 0;
   int w = pick_w(h, ntc, wcap);
@@ -1007,27 +994,11 @@ static int enqueue_factor(mi_gp_handle* h, int noise_form, bool prof) {
   // first kernel of the evaluation: y rows, the bad-pivot word, and theta from the pinned host buffer to theta_dev
   HCK(launch_set_yrows(h->buf.K_dev, h->buf.lda, h->np, h->np, h->buf.y_dev, h->n, s0, h->info_dev, h->theta_host,
                        h->theta_dev, h->ntheta, h->btp), "set_yrows");
-  // Two-stream evaluations of one problem: the first super-panel's factorisation needs only the first 1024 columns of K and
-  // runs on an otherwise idle chip (0.73 ms at N = 16384).  Those columns (the first two 512-column runs of every tile row)
-  // are assembled first; the rest follows on the main stream one workgroup per CU, beside that factorisation (option 24).
-  h->asm_ev_valid = false;
-  const bool two_stream = h->lookahead == 2 || (h->lookahead == 1 && h->ntc >= lookahead_min_tiles(h, h->ntc));
-  // the first super-panel's width, by the rule cholesky() applies (the panel stream is released behind these columns: with a
-  // narrower guess -- a hard-coded 8 until round 5, while option 4 makes the first panel 16 tiles wide -- the panel stream
-  // would factor columns the second assembly launch is still writing)
-  const int w0 = pick_w(h, h->ntc, (two_stream && h->ntc <= NARROW_PANELS_MAX_TILES) ? 4 : 0);
-  const int c0 = (w0 * 128 + 511) / 512;
-  if (h->asm_split && two_stream && !h->btp && h->ntc >= 96 && 4 * c0 < h->ntc) {  // (N = 8192: 5.62 -> 5.65 ms, N = 16384: 26.66 -> 26.57)
-    HCK(launch_assemble(h->spec, h->theta_dev, h->buf.X_dev, h->n, h->buf.X_dev, h->n, h->buf.K_dev, h->buf.lda, h->np,
-                        h->np, 1, noise_form, h->stream, 0, h->diag_dev, h->btp, 0, c0, 0), "assemble (first super-panel)");
-    HCK(hipEventRecord(h->asm_ev, h->stream), "assemble event");
-    h->asm_ev_valid = true;
-    HCK(launch_assemble(h->spec, h->theta_dev, h->buf.X_dev, h->n, h->buf.X_dev, h->n, h->buf.K_dev, h->buf.lda, h->np,
-                        h->np, 1, noise_form, h->stream, 0, h->diag_dev, h->btp, c0, 2147483647, 1), "assemble (rest)");
-  } else {
-    HCK(launch_assemble(h->spec, h->theta_dev, h->buf.X_dev, h->n, h->buf.X_dev, h->n, h->buf.K_dev, h->buf.lda, h->np,
-                        h->np, 1, noise_form, s0, 0, h->diag_dev, h->btp), "assemble");
-  }
+  // (Until round 6 evaluations of 96 tile columns and more assembled the first super-panel's columns first and the rest one
+  // workgroup per CU beside its factorisation, option 24: with the faster assembly it measured level to 0.5 % behind one launch at
+  // N = 12288 .. 20480 and 0.8 % behind at N = 8192, profiles/NOTES_r06.md -- removed.)
+  HCK(launch_assemble(h->spec, h->theta_dev, h->buf.X_dev, h->n, h->buf.X_dev, h->n, h->buf.K_dev, h->buf.lda, h->np,
+                      h->np, 1, noise_form, s0, 0, h->diag_dev, h->btp), "assemble");
   if (prof) (void)hipEventRecord(h->ev[1], s0);
   HCK(cholesky(h, h->buf.K_dev, h->buf.lda, h->ntc + 1, h->ntc), "cholesky");
   if (prof) (void)hipEventRecord(h->ev[2], h->stream);

@@ -51,14 +51,12 @@ constexpr int TPW = 8;                  // tiles per workgroup
 constexpr int SROWS = AT / (256 / DCH);  // rows a thread stages per 64-row block: 8
 
 // RESIDENT: the host guarantees nkern == 1 and d <= DCH (only the prefetching form is compiled), else only the general form.
-// dynamic LDS that makes the kernel's request exceed half a CU (its static image is ~37 KB)
-constexpr size_t ASM_ONE_PER_CU_PAD = 46 * 1024;
 
 template <int KID_STATIC, bool RESIDENT>
 __global__ __launch_bounds__(256, (KID_STATIC >= 0 && KID_STATIC != KID_RATQUAD) ? 3 : 2) void assemble_kernel(
     KernSpec spec, const double* __restrict__ theta_in, const double* __restrict__ X1, int n1, const double* __restrict__ X2, int n2,
     double* __restrict__ K_in, long ldk, int rows_pad, int cols_pad, int sym, int noise_form, int diag_shift,
-    const double* __restrict__ extra_diag, long sK, int stheta, int chunk_lo, int chunk_hi) {
+    const double* __restrict__ extra_diag, long sK, int stheta) {
   const double* __restrict__ theta = theta_in + (long)blockIdx.z * stheta;  // batched evaluation: problem blockIdx.z
   double* __restrict__ K = K_in + (long)blockIdx.z * sK;
   __shared__ __attribute__((aligned(16))) double Xi[AT * DLD];
@@ -83,7 +81,6 @@ __global__ __launch_bounds__(256, (KID_STATIC >= 0 && KID_STATIC != KID_RATQUAD)
     chunk = blockIdx.x % nrun;
     tj_end = cols_pad / AT;
   }
-  if (chunk < chunk_lo || chunk >= chunk_hi) return;  // column-range launch (runs of TPW tiles = 512 columns; uniform per workgroup)
   // gridDim.y > 1 (small problems, round 6): a run is split over that many workgroups -- N = 4096 is 288 runs, one per CU and 40 us
   // each; which workgroup evaluates a tile does not enter its arithmetic
   const int per = TPW / (int)gridDim.y;
@@ -348,8 +345,7 @@ __global__ __launch_bounds__(256) void lml_reduce_kernel(const double* __restric
 
 hipError_t launch_assemble(const KernSpec& spec, const double* theta, const double* X1, int n1, const double* X2,
                            int n2, double* K, long ldk, int rows_pad, int cols_pad, int sym, int noise_form,
-                           hipStream_t stream, int diag_shift, const double* extra_diag, const Batch* bt, int chunk_lo,
-                           int chunk_hi, int one_per_cu) {
+                           hipStream_t stream, int diag_shift, const double* extra_diag, const Batch* bt) {
   int nblk;  // runs of up to TPW tiles of one tile row
   if (sym) {
     const int nt = rows_pad / AT, G = nt / TPW, rem = nt % TPW;
@@ -362,19 +358,16 @@ hipError_t launch_assemble(const KernSpec& spec, const double* theta, const doub
   const bool resident = spec.nkern == 1 && spec.d <= DCH;
   // few runs (N <= 6144 for one problem): split each over 2 / 4 / 8 workgroups so that every CU has several to overlap
   const long nwg = (long)nblk * (bt ? bt->nb : 1);
-  const int split = one_per_cu ? 1 : nwg >= 2048 ? 1 : nwg >= 1024 ? 2 : nwg >= 512 ? 4 : 8;
+  const int split = nwg >= 2048 ? 1 : nwg >= 1024 ? 2 : nwg >= 512 ? 4 : 8;
   const dim3 grid(nblk, split, bt ? bt->nb : 1);
   const long sK = bt ? bt->sK : 0;
   const int sth = bt ? bt->stheta : 0;
-  // one_per_cu: unused dynamic LDS pushes the request over half a CU, so that the panel chain's leaf (which needs a CU to
-  // itself) finds one as soon as a workgroup of this launch retires
-  const size_t pad = one_per_cu ? ASM_ONE_PER_CU_PAD : 0;
 #define MIGP_ASM(KID)                                                                                                              \
   do {                                                                                                                             \
     if (resident)                                                                                                                  \
-      assemble_kernel<KID, true><<<grid, 256, pad, stream>>>(spec, theta, X1, n1, X2, n2, K, ldk, rows_pad, cols_pad, sym, noise_form, ds, ed, sK, sth, chunk_lo, chunk_hi);  \
+      assemble_kernel<KID, true><<<grid, 256, 0, stream>>>(spec, theta, X1, n1, X2, n2, K, ldk, rows_pad, cols_pad, sym, noise_form, ds, ed, sK, sth);  \
     else                                                                                                                           \
-      assemble_kernel<KID, false><<<grid, 256, pad, stream>>>(spec, theta, X1, n1, X2, n2, K, ldk, rows_pad, cols_pad, sym, noise_form, ds, ed, sK, sth, chunk_lo, chunk_hi); \
+      assemble_kernel<KID, false><<<grid, 256, 0, stream>>>(spec, theta, X1, n1, X2, n2, K, ldk, rows_pad, cols_pad, sym, noise_form, ds, ed, sK, sth); \
   } while (0)
   if (spec.nkern != 1) MIGP_ASM(-1);
   else if (spec.kid[0] == KID_RBF) MIGP_ASM(KID_RBF);
@@ -384,20 +377,6 @@ hipError_t launch_assemble(const KernSpec& spec, const double* theta, const doub
   else MIGP_ASM(KID_RATQUAD);
 #undef MIGP_ASM
   return hipGetLastError();
-}
-
-hipError_t assemble_enable_lds() {
-  const int ldsb = (int)ASM_ONE_PER_CU_PAD;
-#define MIGP_ATTR(KID)                                                                                                      \
-  do {                                                                                                                      \
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_kernel<KID, true>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);  \
-    if (e != hipSuccess) return e;                                                                                          \
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_kernel<KID, false>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);            \
-    if (e != hipSuccess) return e;                                                                                          \
-  } while (0)
-  MIGP_ATTR(-1); MIGP_ATTR(KID_RBF); MIGP_ATTR(KID_MATERN52); MIGP_ATTR(KID_MATERN32); MIGP_ATTR(KID_EXPONENTIAL); MIGP_ATTR(KID_RATQUAD);
-#undef MIGP_ATTR
-  return hipSuccess;
 }
 
 hipError_t launch_set_yrows(double* K, long ldk, int row0, int cols_pad, const double* y, int n, hipStream_t stream,

@@ -140,10 +140,7 @@ struct KernSpec {
 hipError_t launch_assemble(const KernSpec& spec, const double* theta, const double* X1, int n1, const double* X2,
                            int n2, double* K, long ldk, int rows_pad, int cols_pad, int sym, int noise_form,
                            hipStream_t stream, int diag_shift = -2147483647 - 1, const double* extra_diag = nullptr,
-                           const Batch* bt = nullptr, int chunk_lo = 0, int chunk_hi = 2147483647, int one_per_cu = 0);
-// chunk_lo / chunk_hi: only the runs of 512 columns [512 chunk_lo, 512 chunk_hi) (the driver assembles the first super-panel's
-// columns first and the rest beside its factorisation); one_per_cu: one workgroup per CU (room for the panel chain)
-hipError_t assemble_enable_lds();
+                           const Batch* bt = nullptr);
 // diag_shift (sym=0 only): local element (i, j) is on the global diagonal when i + diag_shift == j
 // (rectangular blocks of a distributed covariance); the default means "no diagonal" (cross-covariance).
 // info (optional): reset to 0x7f7f7f7f ("no bad pivot") by the same launch

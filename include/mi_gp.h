@@ -153,8 +153,6 @@ MI_GP_API int mi_gp_predict_grad(mi_gp_handle* h, const double* Xnew_dev, int m,
  *   20 trailing tile columns from which the next super-panel's update rides at the head of the trailing update's tile
  *      enumeration instead of in launches of its own (default 72, 0: never)
  *   21 trailing tile columns at or below which a two-stream factorisation continues on the main stream alone (default 8)
- *   24 large two-stream evaluations assemble the first super-panel's columns first and the rest of K beside its
- *      factorisation, one workgroup per CU (default 1)
  *   26 cross-stream edges of the factorisation: 0 hipEventRecord + hipStreamWaitEvent; 1 stream memory operations --
  *      hipStreamWriteValue32 behind the producer's work, hipStreamWaitValue32 in front of the consumer's (4-5 us per edge
  *      instead of 11-12 on MI355X; N = 6144 3.40 -> 3.26 ms); 2 (default) the same protocol with the PANEL stream's halves
@@ -197,12 +195,13 @@ MI_GP_API int mi_gp_predict_grad(mi_gp_handle* h, const double* Xnew_dev, int m,
  *   45 problems that run in column mode from the start on two streams queue their first two kernels (theta / y rows, assembly) on
  *      the PANEL stream, so that the first leaf follows them in stream order instead of behind a cross-stream edge (default 1;
  *      N = 1024 -3 %); scheduling only
- * 8, 14, 16, 18, 19, 21, 24, 26, 27, 30, 31, 38 and 45 only change scheduling (bit-identical results); 20 moves tiles between the
+ * 8, 14, 16, 18, 19, 21, 26, 27, 30, 31, 38 and 45 only change scheduling (bit-identical results); 20 moves tiles between the
  * two GEMM kernels (same k order); 2, 4-7, 9, 32, 35 and 37 regroup sums (agreement to rounding), and so does 0 where it changes
  * the super-panel width (20 to 60 tile columns).
  * Unknown ids return -1.  (Round 1's options 1, 3, 10-13 -- GEMM variants, hipGraph replay, persistent bulk kernels,
  * exclusive leaf, fused leaf + strip -- and round 5's 29, 33, 34, 36, 39 -- forms that lost their A/B: the next-panel update's
- * occupancy as a knob, strided thin updates, that update in pieces, 64x128 tiles -- are gone with the code they selected.) */
+ * occupancy as a knob, strided thin updates, that update in pieces, 64x128 tiles -- and round 3's 24, the assembly in two parts,
+ * which stopped paying in round 6, are gone with the code they selected.) */
 MI_GP_API int mi_gp_set_option(mi_gp_handle* h, int what, int value);
 /* current value of a knob, the library's own defaults included; 40 (read-only): 1 once the handle has switched its cross-stream
  * edges to events by itself (option 26) */

@@ -102,10 +102,10 @@ def test_ragged_large_size_through_the_split_and_merged_launches():
     gp = MiGP(X, y, "Matern52", need_grad=False)
     v0 = gp.lml(theta)
     assert abs(v0 - ref) <= 1e-10 * abs(ref), (v0, ref)
-    for opts in ({18: 0}, {20: 0}, {21: 0}, {18: 0, 20: 0, 21: 0}, {18: 1024, 19: 256, 20: 40}, {26: 0}, {26: 1}, {26: 0, 21: 16, 24: 0}):
+    for opts in ({18: 0}, {20: 0}, {21: 0}, {18: 0, 20: 0, 21: 0}, {18: 1024, 19: 256, 20: 40}, {26: 0}, {26: 1}, {26: 0, 21: 16}):
         for k, v in opts.items():
             gp.set_option(k, v)
         assert gp.lml(theta) == v0, opts
-        for k, v in {18: 1536, 19: 1024, 20: 72, 21: 8, 24: 1, 26: 2}.items():
+        for k, v in {18: 1536, 19: 1024, 20: 72, 21: 8, 26: 2}.items():
             gp.set_option(k, v)
     gp.close()

@@ -167,25 +167,6 @@ def test_six_handles_evaluating_concurrently_on_two_streams_each():
         g.close()
 
 
-def test_assembly_split_follows_the_first_super_panel_width():
-    """with option 4 the first super-panel is 16 tiles wide; the split assembly (option 24) used to release the panel
-    stream behind 8 tiles' columns only.  Same bits with the split on and off."""
-    MiGP, orc = _mods()
-    N, d = 12288, 8
-    X, y = orc.synth_problem(N, d, seed=11)
-    theta = orc.synth_theta(d)
-    gp = MiGP(X, y, "RBF", need_grad=False)
-    gp.set_option(4, 64)  # 16-tile super-panels while more than 64 tile columns remain
-    gp.set_option(24, 0)
-    a = gp.lml(theta)
-    gp.set_option(24, 1)
-    vals = [gp.lml(theta) for _ in range(4)]
-    assert gp.info == 0 and all(v == a for v in vals), (a, vals)
-    ref = orc.lml(X, y, ["RBF"], [], theta)
-    assert abs(a - ref) <= 1e-10 * abs(ref)
-    gp.close()
-
-
 def test_early_inverse_levels_leave_the_gradient_bit_identical():
     """Option 30: the first block-doubling levels of U = L^-T run inside the factorisation's tail on the main stream
     (LML + gradient from 64 tile columns on) -- same launches per tile, regrouped over node batches: same bits."""

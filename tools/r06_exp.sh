@@ -2,10 +2,10 @@
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd $ROOT
 {
-timeout -k 10 200 python tools/dev_ab_opts.py 16384 16 Matern52 "24=1" "24=0" "24=1" "24=0 " || exit 1
-timeout -k 10 200 python tools/dev_ab_opts.py 16384 8 RBF "24=1" "24=0" || exit 1
-timeout -k 10 200 python tools/dev_ab_opts.py 14336 8 RBF "24=1" "24=0" || exit 1
-timeout -k 10 200 python tools/dev_ab_opts.py 16384 16 Matern52 --grad "24=1" "24=0" || exit 1
-timeout -k 10 200 python tools/dev_ab_opts.py 20480 8 RBF "24=1" "24=0" || exit 1
-} > gpurun_out/r06_asm_split2.txt 2>&1
-grep median gpurun_out/r06_asm_split2.txt
+timeout -k 10 200 python tools/dev_ab_opts.py 16384 16 Matern52 "47=0" "47=4" "47=2" || exit 1
+timeout -k 10 200 python tools/dev_ab_opts.py 8192 8 RBF "47=0" "47=4" "47=2" || exit 1
+timeout -k 10 200 python tools/dev_ab_opts.py 12288 8 RBF "47=0" "47=4" "47=2" || exit 1
+timeout -k 10 200 python tools/dev_ab_opts.py 20480 8 RBF "47=0" "47=4" || exit 1
+timeout -k 10 200 python tools/dev_ab_opts.py 6144 8 RBF "47=0" "47=2" || exit 1
+} > gpurun_out/r06_first_w.txt 2>&1
+grep -E "median|Error|error" gpurun_out/r06_first_w.txt

@@ -135,14 +135,18 @@ def test_default_schedule_terminates_under_serialised_dispatch(env):
         assert at_create == 0 and demoted == 0 and mode == 2, line
 
 
-def test_six_handles_evaluating_concurrently_on_two_streams_each():
+@pytest.mark.parametrize("N,nh", [(3072, 6), (640, 6), (640, 10)])
+def test_handles_evaluating_concurrently_on_two_streams_each(N, nh):
     """Six handles x two streams with in-kernel polls (option 26 = 2): no poll-limit error, every value equal to the serial
-    schedule's (include/mi_gp.h documents six as the tested limit for mode 2)."""
+    schedule's (include/mi_gp.h documents six as the tested limit for mode 2).  N = 640 is five tile columns -- on two streams
+    since round 6.  TEN handles are beyond the documented limit: a handle whose poll runs into its limit there demotes itself to
+    event edges and evaluates again inside the call (option 40), so the values are still the serial schedule's and no call fails."""
     MiGP, orc = _mods()
-    N, d = 3072, 6  # 24 tile columns: the two-stream driver
+    d = 6  # (N = 3072: 24 tile columns, the two-stream driver in column mode from the start)
     X, y = orc.synth_problem(N, d, seed=9)
     thetas = [orc.synth_theta(d, kv=1.2 + 0.05 * i) for i in range(12)]
-    gps = [MiGP(X, y, "Matern52", need_grad=False) for _ in range(6)]
+    gps = [MiGP(X, y, "Matern52", need_grad=False) for _ in range(nh)]
+    assert all(g.get_option(0, 1) == 1 for g in gps)
     serial = [gps[0].lml(t) for t in thetas]
     out = [[None] * len(thetas) for _ in gps]
     errs = []
@@ -163,6 +167,8 @@ def test_six_handles_evaluating_concurrently_on_two_streams_each():
     assert not errs, errs
     for i in range(len(gps)):
         assert out[i] == serial
+    if nh <= 6:
+        assert [g.get_option(40, 0) for g in gps] == [0] * nh  # nobody had to give up the polls
     for g in gps:
         g.close()
 

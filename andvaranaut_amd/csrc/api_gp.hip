@@ -54,6 +54,7 @@ struct mi_gp_handle {
   int rl_group;                     // option 38: column mode of a BATCH applies the main stream's k = 128 updates to the far columns in
                                     // k-segmented launches of this many columns (same bits, the trailing matrices read and written once per group)
   int rl_cols;                      // option 37: the last rl_cols tile columns are factored COLUMN BY COLUMN (cholesky(): column mode); 0: never
+  int rl_whole;                     // option 46: problems of up to this many tile columns run in column mode from the start (whole_columns())
   int ext_rows;                     // option 35: a super-panel with at most this many tile rows below it also applies its updates to
                                     // the NEXT super-panel's first tile column, level by level (chol_panel's nx); 0: never
   int done_col, done_slot;          // the update behind the strip of tile column done_col raises this slot ("super-panel done")
@@ -245,6 +246,7 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   h->demoted = false;
   h->thin_max_wg = 2048;
   h->rl_cols = 24;
+  h->rl_whole = 31;
   h->start_on_panel = 1;
   h->asm_on_panel = false;
   h->rl_group = 8;
@@ -345,6 +347,7 @@ extern "C" int mi_gp_set_option(mi_gp_handle* h, int what, int value) {
   else if (what == 32) h->thin_max_wg = value < 0 ? 0 : value;
   else if (what == 35) h->ext_rows = value < 0 ? 0 : value;
   else if (what == 37) h->rl_cols = value < 0 ? 0 : value;
+  else if (what == 46) h->rl_whole = value < 0 ? 0 : value;
   else if (what == 38) h->rl_group = value < 1 ? 1 : value > 8 ? 8 : value;
   else if (what == 45) h->start_on_panel = value ? 1 : 0;
   else if (what == 9) h->tail_small = value ? 1 : 0;
@@ -379,6 +382,7 @@ extern "C" int mi_gp_get_option(mi_gp_handle* h, int what, int* value) {
     case 32: *value = h->thin_max_wg; break;
     case 35: *value = h->ext_rows; break;
     case 37: *value = h->rl_cols; break;
+    case 46: *value = h->rl_whole; break;
     case 38: *value = h->rl_group; break;
     case 45: *value = h->start_on_panel; break;
     case 40: *value = h->demoted ? 1 : 0; break;
@@ -607,6 +611,14 @@ constexpr int LOOKAHEAD_MIN_TILES = 20;  // round 4: with the single-stream tail
 // N = 384 0.124 vs 0.124 ms, 512 0.168 vs 0.158, 640 0.211 vs 0.195, 768 0.258 vs 0.236, 896 0.305 vs 0.273); it was 8.
 constexpr int COLUMN_MODE_MIN_TILES = 4;
 static int lookahead_min_tiles(const mi_gp_handle* h, int ntc);
+// Column mode for the WHOLE problem: up to rl_cols tile columns by the tail rule itself, and (round 6, option 46) up to rl_whole = 31:
+// for 25 .. 31 tile columns a first panel of 1 .. 7 columns with its entry stall costs more than the main stream's lag behind
+// the chain in the first columns (24 / 31: N = 3200 0.994 -> 0.946 ms, 3456 1.101 -> 1.059, 3584 1.156 -> 1.141, 3840 1.234 -> 1.209,
+// 3968 1.292 -> 1.267; batches of 8 -1.7 .. -3.3 %).  At 32 columns it turns: N = 4096 1.416 -> 1.454 (a batch of 8 would still
+// gain 2.7 %, but the rule is one of the shape alone, and the single evaluation decides it).
+static bool whole_columns(const mi_gp_handle* h, int ntc) {
+  return h->rl_cols > 0 && (ntc <= h->rl_cols || ntc <= h->rl_whole);
+}
 
 static hipError_t u_levels(mi_gp_handle* h, int final_cols, int max_s);
 
@@ -716,7 +728,7 @@ static hipError_t chol_columns(mi_gp_handle* h, double* A, long lda, int ntr, in
 }
 
 static int lookahead_min_tiles(const mi_gp_handle* h, int ntc) {
-  return (h->rl_cols > 0 && ntc <= h->rl_cols) ? COLUMN_MODE_MIN_TILES : LOOKAHEAD_MIN_TILES;
+  return whole_columns(h, ntc) ? COLUMN_MODE_MIN_TILES : LOOKAHEAD_MIN_TILES;
 }
 
 static hipError_t cholesky_enqueue(mi_gp_handle* h, double* A, long lda, int ntr, int ntc);
@@ -791,7 +803,7 @@ static hipError_t cholesky_enqueue(mi_gp_handle* h, double* A, long lda, int ntr
     return hand_off(h, T, P);
   };
   // column mode (chol_columns) for the last rl_cols tile columns -- a rule of the shape alone, like the extended panels
-  auto rl = [&](int c0) { return h->rl_cols > 0 && c0 < ntc && ntc - c0 <= h->rl_cols; };
+  auto rl = [&](int c0) { return h->rl_cols > 0 && c0 < ntc && (ntc - c0 <= h->rl_cols || (c0 == 0 && whole_columns(h, ntc))); };
   if (rl(0)) {
     CKE(chol_columns(h, A, lda, ntr, ntc, 0, T, P, false));
     if (P != T) CKE(hand_off(h, P, T));
@@ -979,7 +991,7 @@ static hipError_t cholesky_enqueue(mi_gp_handle* h, double* A, long lda, int ntr
 // Kernels of one evaluation: assembly, factorisation of the augmented trapezoid [[K],[y^T]] (L ends
 // up in K_dev, beta = L^-1 y in row np), reduction.
 static int enqueue_factor(mi_gp_handle* h, int noise_form, bool prof) {
-  // Problems that run in column mode from the start on two streams (8 .. rl_cols tile columns; round 6): the evaluation's first two
+  // Problems that run in column mode from the start on two streams (4 .. 28 tile columns, whole_columns(); round 6): the evaluation's first two
   // kernels go to the PANEL stream, so that the first leaf follows the assembly in stream order instead of behind a cross-stream
   // edge (~10 us of a 0.3 ms evaluation at N = 1024).  The main stream's first launch waits for a leaf's start signal anyway,
   // and every API call ends with both streams drained.  Same launches: scheduling only.  (The rule is cholesky_enqueue's.)
@@ -987,7 +999,7 @@ static int enqueue_factor(mi_gp_handle* h, int noise_form, bool prof) {
     const int nb_ = h->btp ? h->btp->nb : 1;
     const bool la_ = h->lookahead == 2 || (h->lookahead == 1 && h->ntc >= lookahead_min_tiles(h, h->ntc)) ||
                      (h->lookahead == 1 && nb_ >= 2 && h->ntc >= (nb_ >= 8 ? 20 : 24));
-    h->asm_on_panel = la_ && h->rl_cols > 0 && h->ntc <= h->rl_cols && h->start_on_panel;
+    h->asm_on_panel = la_ && whole_columns(h, h->ntc) && h->start_on_panel;
   }
   const hipStream_t s0 = h->asm_on_panel ? h->pstream : h->stream;
   if (prof) (void)hipEventRecord(h->ev[0], s0);

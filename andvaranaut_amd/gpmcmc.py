@@ -594,7 +594,7 @@ class GPMCMC(ConsumersMixin):
                     # size = 1, super-panel width by size = 0)
                     before = (h.get_option(2, 0), h.get_option(0, 1))
                     if 20 <= ntc <= 60:  # (api_gp.hip NARROW_PANELS_MAX_TILES: above it both schedules use 8-tile super-panels;
-                        h.set_option(2, 4)  # up to 24 tile columns the whole problem runs in column mode: no panels at all)
+                        h.set_option(2, 4)  # up to 31 tile columns the whole problem runs in column mode: no panels at all)
                     h.set_option(0, 0)
                 try:
                     lik = self._warp_likelihood(h, x, y, xin, iwgp, cwgp) if (iwgp or cwgp) else None

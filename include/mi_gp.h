@@ -189,6 +189,9 @@ MI_GP_API int mi_gp_predict_grad(mi_gp_handle* h, const double* Xnew_dev, int m,
  *      main stream, a column behind the chain.  Problems of up to that many tile columns run in it from the start, on two
  *      streams from 4 tile columns on (round 6; it was 8 before option 45).  Regroups sums (agreement to rounding); a rule of the shape alone: one stream, two
  *      streams and a batch return the same bits.  N = 2048 0.665 -> 0.619 ms, 3072 0.981 -> 0.920, 4096 1.471 -> 1.443.
+ *   46 problems of up to this many tile columns run in column mode from the START even where option 37 would put panels in
+ *      front of it (default 31 = N <= 3968; ignored when 37 is 0).  Regroups sums like 37, a rule of the shape alone.
+ *      N = 3200 0.994 -> 0.946 ms, 3968 1.292 -> 1.267; at 32 tile columns it turns (N = 4096 1.416 -> 1.454).
  *   38 column mode of a BATCH: the main stream applies its k = 128 updates to the columns behind the chain's next one in
  *      k-segmented launches of this many columns (default 8; 1: one launch per column as for a single evaluation).  The tile
  *      takes every 128-column partial sum as a launch of its own would round it: same bits, scheduling only.
@@ -196,7 +199,7 @@ MI_GP_API int mi_gp_predict_grad(mi_gp_handle* h, const double* Xnew_dev, int m,
  *      the PANEL stream, so that the first leaf follows them in stream order instead of behind a cross-stream edge (default 1;
  *      N = 1024 -3 %); scheduling only
  * 8, 14, 16, 18, 19, 21, 26, 27, 30, 31, 38 and 45 only change scheduling (bit-identical results); 20 moves tiles between the
- * two GEMM kernels (same k order); 2, 4-7, 9, 32, 35 and 37 regroup sums (agreement to rounding), and so does 0 where it changes
+ * two GEMM kernels (same k order); 2, 4-7, 9, 32, 35, 37 and 46 regroup sums (agreement to rounding), and so does 0 where it changes
  * the super-panel width (20 to 60 tile columns).
  * Unknown ids return -1.  (Round 1's options 1, 3, 10-13 -- GEMM variants, hipGraph replay, persistent bulk kernels,
  * exclusive leaf, fused leaf + strip -- and round 5's 29, 33, 34, 36, 39 -- forms that lost their A/B: the next-panel update's

@@ -195,9 +195,10 @@ def test_early_inverse_levels_leave_the_gradient_bit_identical():
     gp.close()
 
 
-@pytest.mark.parametrize("N,d", [(1500, 4), (3000, 6), (4300, 5), (8320, 8)])
+@pytest.mark.parametrize("N,d", [(1500, 4), (3000, 6), (3700, 5), (4300, 5), (8320, 8)])
 def test_column_mode_and_extended_panels_return_the_same_bits_on_every_schedule(N, d):
-    """Round 5: the last 24 tile columns are factored column by column (option 37), the super-panels in front of them also
+    """Round 5: the last 24 tile columns are factored column by column (option 37; problems of up to 31 tile columns as a whole
+    since round 6, option 46: N = 3700 is 29), the super-panels in front of them also
     update the next panel's first column (option 35), short in-panel updates run on the thin kernel (option 32).  All three are
     rules of the SHAPE: one stream (option 0 = 0), forced two streams (0 = 2), event edges instead of stream memory
     operations (26 = 0 / 1), the other scheduling knobs -- every schedule returns the default's bits, LML and gradient."""
@@ -234,10 +235,12 @@ def test_round5_arithmetic_options_agree_to_rounding_and_off_is_the_round4_chain
     ref = orc.lml(X, y, ["RBF"], [], theta)
     gp = MiGP(X, y, "RBF", need_grad=False)
     vals = []
-    for o32, o35, o37 in [(2048, 32, 24), (0, 32, 24), (2048, 0, 24), (2048, 32, 0), (0, 0, 0), (2048, 64, 34), (64, 8, 12)]:
+    for o32, o35, o37, o46 in [(2048, 32, 24, 31), (0, 32, 24, 31), (2048, 0, 24, 31), (2048, 32, 0, 31), (0, 0, 0, 31), (2048, 64, 34, 31), (64, 8, 12, 31),
+                               (2048, 32, 24, 34), (2048, 32, 12, 40)]:  # (46: the whole problem, 34 tile columns, in column mode)
         gp.set_option(32, o32)
         gp.set_option(35, o35)
         gp.set_option(37, o37)
+        gp.set_option(46, o46)
         v = gp.lml(theta)
         assert abs(v - ref) <= 1e-10 * abs(ref), (o32, o35, o37)
         vals.append(v)
@@ -249,9 +252,9 @@ def test_round5_arithmetic_options_agree_to_rounding_and_off_is_the_round4_chain
     gp.close()
 
 
-@pytest.mark.parametrize("ntc,ragged", [(3, 0), (4, -20), (5, 0), (7, 0), (8, -37), (9, 0), (19, -1), (20, 0), (23, -100), (24, 0), (25, -3), (28, 0), (29, -64), (33, 0)])
+@pytest.mark.parametrize("ntc,ragged", [(3, 0), (4, -20), (5, 0), (7, 0), (8, -37), (9, 0), (19, -1), (20, 0), (23, -100), (24, 0), (25, -3), (28, 0), (29, -64), (31, 0), (32, -7), (33, 0)])
 def test_tile_column_counts_around_the_round5_thresholds(ntc, ragged):
-    """One stream below 4 tile columns (8 until round 6), column mode from the start up to 24, an entry into it behind one or more super-panels
+    """One stream below 4 tile columns (8 until round 6), column mode from the start up to 31 (24 until round 6), an entry into it behind one or more super-panels
     above, extended panels from 20: every boundary of those rules (and ragged last tiles) against the oracle, LML and gradient,
     and a batch of three against the single entry point."""
     MiGP, orc = _mods()

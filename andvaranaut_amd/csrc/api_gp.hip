@@ -765,7 +765,7 @@ static hipError_t cholesky_enqueue(mi_gp_handle* h, double* A, long lda, int ntr
     if (h->asm_on_panel && P == h->pstream) {}  // (the assembly is in front of the chain on this very stream)
     else CKE(hand_off(h, T, P));
   } else if (h->asm_on_panel) {
-    CKE(hand_off(h, h->pstream, T));  // (cannot happen: enqueue_factor decides by the rule below; kept for safety)
+    CKE(hand_off(h, h->pstream, T));  // (cannot happen: enqueue_factor decides by the same rule; kept for safety)
   }
   h->asm_on_panel = false;
   const int wcap = (la_single && ntc <= NARROW_PANELS_MAX_TILES) ? 4 : 0;
@@ -991,15 +991,17 @@ static hipError_t cholesky_enqueue(mi_gp_handle* h, double* A, long lda, int ntr
 // Kernels of one evaluation: assembly, factorisation of the augmented trapezoid [[K],[y^T]] (L ends
 // up in K_dev, beta = L^-1 y in row np), reduction.
 static int enqueue_factor(mi_gp_handle* h, int noise_form, bool prof) {
-  // Problems that run in column mode from the start on two streams (4 .. 28 tile columns, whole_columns(); round 6): the evaluation's first two
-  // kernels go to the PANEL stream, so that the first leaf follows the assembly in stream order instead of behind a cross-stream
-  // edge (~10 us of a 0.3 ms evaluation at N = 1024).  The main stream's first launch waits for a leaf's start signal anyway,
-  // and every API call ends with both streams drained.  Same launches: scheduling only.  (The rule is cholesky_enqueue's.)
+  // Two-stream evaluations (round 6): the evaluation's first two kernels go to the PANEL stream, so that the first leaf follows the
+  // assembly in stream order instead of behind a cross-stream edge (~10 us: N = 1024 0.335 -> 0.308 ms, 2048 0.651 -> 0.605; from 32
+  // tile columns on, where a panel and not a column comes first, it is 0.1-0.4 %: N = 4096 1.411 -> 1.405, LML + gradient 2.515 -> 2.473).
+  // The main stream's first launch waits for the panel stream anyway (a leaf's start signal in column mode, the first panel's
+  // end otherwise), and every API call ends with both streams drained.  Same launches: scheduling only.  (The rule is
+  // cholesky_enqueue's.)
   {
     const int nb_ = h->btp ? h->btp->nb : 1;
     const bool la_ = h->lookahead == 2 || (h->lookahead == 1 && h->ntc >= lookahead_min_tiles(h, h->ntc)) ||
                      (h->lookahead == 1 && nb_ >= 2 && h->ntc >= (nb_ >= 8 ? 20 : 24));
-    h->asm_on_panel = la_ && whole_columns(h, h->ntc) && h->start_on_panel;
+    h->asm_on_panel = la_ && h->start_on_panel;
   }
   const hipStream_t s0 = h->asm_on_panel ? h->pstream : h->stream;
   if (prof) (void)hipEventRecord(h->ev[0], s0);

@@ -195,9 +195,9 @@ MI_GP_API int mi_gp_predict_grad(mi_gp_handle* h, const double* Xnew_dev, int m,
  *   38 column mode of a BATCH: the main stream applies its k = 128 updates to the columns behind the chain's next one in
  *      k-segmented launches of this many columns (default 8; 1: one launch per column as for a single evaluation).  The tile
  *      takes every 128-column partial sum as a launch of its own would round it: same bits, scheduling only.
- *   45 problems that run in column mode from the start on two streams queue their first two kernels (theta / y rows, assembly) on
- *      the PANEL stream, so that the first leaf follows them in stream order instead of behind a cross-stream edge (default 1;
- *      N = 1024 -3 %); scheduling only
+ *   45 two-stream evaluations queue their first two kernels (theta / y rows, assembly) on the PANEL stream, so that the first
+ *      leaf follows them in stream order instead of behind a cross-stream edge (default 1; N = 1024 -7 %, 2048 -4 %, from 32 tile
+ *      columns on 0.1-0.4 %); scheduling only
  * 8, 14, 16, 18, 19, 21, 26, 27, 30, 31, 38 and 45 only change scheduling (bit-identical results); 20 moves tiles between the
  * two GEMM kernels (same k order); 2, 4-7, 9, 32, 35, 37 and 46 regroup sums (agreement to rounding), and so does 0 where it changes
  * the super-panel width (20 to 60 tile columns).

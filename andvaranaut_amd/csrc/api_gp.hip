@@ -51,6 +51,10 @@ struct mi_gp_handle {
   int thin_max_wg;                  // option 32: in-panel updates of at most this many 16-row x 128-column slices (k = 128, at most
                                     // THIN_MAX_COLS tile columns) run on the thin kernel (thin_f64.hip); 0: never
   int start_on_panel;               // option 45: see enqueue_factor (default 1; scheduling only)
+  int spin_us;                      // option 47: wait_evaluation() spins on the evaluation's sequence word for up to this many us (0: never)
+  double eval_seq;                  // sequence number of the evaluation in flight (published by its last kernel)
+  int spin_backoff;                 // evaluations left that go straight to hipStreamSynchronize (the last spin ran into its budget)
+  unsigned spin_hits;               // spin waits that saw the word (every 256th synchronises the stream all the same)
   int rl_group;                     // option 38: column mode of a BATCH applies the main stream's k = 128 updates to the far columns in
                                     // k-segmented launches of this many columns (same bits, the trailing matrices read and written once per group)
   int rl_cols;                      // option 37: the last rl_cols tile columns are factored COLUMN BY COLUMN (cholesky(): column mode); 0: never
@@ -248,6 +252,10 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   h->rl_cols = 24;
   h->rl_whole = 31;
   h->start_on_panel = 1;
+  h->spin_us = 2000;
+  h->eval_seq = 0.0;
+  h->spin_backoff = 0;
+  h->spin_hits = 0;
   h->asm_on_panel = false;
   h->rl_group = 8;
   h->ext_rows = 32;
@@ -275,9 +283,10 @@ extern "C" int mi_gp_create(const mi_gp_config* cfg, mi_gp_handle** out) {
   if (e == hipSuccess) e = hipMalloc(&h->sig_dev, sizeof(unsigned) * SIG_SLOTS);
   if (e == hipSuccess) e = hipMemset(h->sig_dev, 0, sizeof(unsigned) * SIG_SLOTS);
   if (e == hipSuccess) e = hipMalloc(&h->lr_part_dev, sizeof(double) * 2 * LML_REDUCE_BLOCKS);
-  if (e == hipSuccess) e = hipMalloc(&h->lr_sync_dev, sizeof(unsigned));
-  if (e == hipSuccess) e = hipMemset(h->lr_sync_dev, 0, sizeof(unsigned));
+  if (e == hipSuccess) e = hipMalloc(&h->lr_sync_dev, sizeof(unsigned) * 2);  // [0] lml_reduce's ticket, [1] grad_final's
+  if (e == hipSuccess) e = hipMemset(h->lr_sync_dev, 0, sizeof(unsigned) * 2);
   if (e == hipSuccess) e = hipHostMalloc(&h->out_host, sizeof(double) * 16);
+  if (e == hipSuccess) memset(h->out_host, 0, sizeof(double) * 16);  // (the sequence words: wait_evaluation())
   if (e == hipSuccess) e = hipHostMalloc(&h->theta_host, sizeof(double) * h->ntheta);
   for (int i = 0; i < 8 && e == hipSuccess; ++i) e = hipEventCreate(&h->ev[i]);
   if (e == hipSuccess) e = gemm_f64_enable_lds();
@@ -350,6 +359,7 @@ extern "C" int mi_gp_set_option(mi_gp_handle* h, int what, int value) {
   else if (what == 46) h->rl_whole = value < 0 ? 0 : value;
   else if (what == 38) h->rl_group = value < 1 ? 1 : value > 8 ? 8 : value;
   else if (what == 45) h->start_on_panel = value ? 1 : 0;
+  else if (what == 47) { h->spin_us = value < 0 ? 0 : value; h->spin_backoff = 0; }
   else if (what == 9) h->tail_small = value ? 1 : 0;
   else {
     snprintf(h->err, sizeof(h->err), "mi_gp_set_option: unknown option %d", what);
@@ -385,6 +395,7 @@ extern "C" int mi_gp_get_option(mi_gp_handle* h, int what, int* value) {
     case 46: *value = h->rl_whole; break;
     case 38: *value = h->rl_group; break;
     case 45: *value = h->start_on_panel; break;
+    case 47: *value = h->spin_us; break;
     case 40: *value = h->demoted ? 1 : 0; break;
     default:
       snprintf(h->err, sizeof(h->err), "mi_gp_get_option: unknown option %d", what);
@@ -1017,8 +1028,9 @@ static int enqueue_factor(mi_gp_handle* h, int noise_form, bool prof) {
   HCK(cholesky(h, h->buf.K_dev, h->buf.lda, h->ntc + 1, h->ntc), "cholesky");
   if (prof) (void)hipEventRecord(h->ev[2], h->stream);
   // the scalars go straight to the pinned host buffer (device-visible): no download launch behind the reduction
+  h->eval_seq += 1.0;  // (exact in a double for 2^53 evaluations)
   HCK(launch_lml_reduce(h->buf.K_dev, h->buf.lda, h->buf.K_dev + (long)h->np * h->buf.lda, h->n, h->out_host, h->stream, h->info_dev,
-                        h->btp, h->lr_part_dev, h->lr_sync_dev), "lml_reduce");
+                        h->btp, h->lr_part_dev, h->lr_sync_dev, h->eval_seq), "lml_reduce");
   if (prof) (void)hipEventRecord(h->ev[3], h->stream);
   return 0;
 }
@@ -1070,6 +1082,40 @@ static int poll_timeout(mi_gp_handle* h, int attempt) {
   return -2;
 }
 
+// The host's end of an evaluation.  The evaluation's last kernel -- lml_reduce, or the gradient's final reduction -- publishes
+// the evaluation's sequence number in the pinned result buffer (out[4] / out[5] of every problem), released at system scope
+// behind the scalars it stands for.  hipStreamSynchronize costs a round trip of 6-8 us behind that kernel's end (a completion
+// signal and a blocked wait); spinning on the word sees it within the PCIe write latency: N = 128 0.056 -> 0.051 ms, 512 0.161 ->
+// 0.153, 1024 0.310 -> 0.291, 4096 1.424 -> 1.387.  The spin has a budget (option 47, default 2 ms); an evaluation that runs
+// into it synchronises the stream as before and the handle's next 15 evaluations do not spin at all, so a long evaluation
+// costs a core 2 ms in 16 calls, not its run time.  The word is the LAST thing the evaluation's last kernel does, and that
+// kernel writes nothing but the pinned result buffer: after a successful spin every device-side read and write of the
+// evaluation is complete and only the kernel's RETIREMENT may be outstanding.  Everything this library does next goes through
+// the same stream (in order); the paths that need idle streams (time-outs, the epoch wrap, profiling events, destruction)
+// synchronise them themselves; every 256th spin synchronises the stream all the same (keeps the runtime's bookkeeping of
+// completed launches short).  The panel stream is idle by then: the main stream's last kernels wait for it.
+static hipError_t wait_evaluation(mi_gp_handle* h, int what, int k, bool prof) {
+  bool seen = false;
+  if (h->spin_us > 0 && !prof && h->spin_backoff == 0) {
+    long long want;
+    memcpy(&want, &h->eval_seq, sizeof(want));
+    const double* f = h->out_host + (what == 2 ? 5 : 4);
+    const auto t0 = std::chrono::steady_clock::now();
+    int p = 0;
+    for (unsigned it = 1;; ++it) {
+      while (p < k && __atomic_load_n(reinterpret_cast<const long long*>(f + 16 * p), __ATOMIC_ACQUIRE) == want) ++p;
+      if (p == k) { seen = true; break; }
+      __builtin_ia32_pause();
+      if ((it & 63u) == 0 && std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > h->spin_us) break;
+    }
+    if (!seen) h->spin_backoff = 15;
+    else if ((++h->spin_hits & 255u) == 0) seen = false;
+  } else if (h->spin_backoff > 0) {
+    --h->spin_backoff;
+  }
+  return seen ? hipSuccess : hipStreamSynchronize(h->stream);
+}
+
 static int factor_internal(mi_gp_handle* h, const double* theta, int what) {
   h->factored = false;
   h->have_kinv = false;
@@ -1085,7 +1131,7 @@ static int factor_internal(mi_gp_handle* h, const double* theta, int what) {
     const auto t_enq0 = std::chrono::steady_clock::now();
     if (int r = run_evaluation(h, what)) return r;
     h->t_enqueue_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enq0).count();
-    HCK(hipStreamSynchronize(h->stream), "stream sync");
+    HCK(wait_evaluation(h, what, 1, prof), "stream sync");
     if ((int)h->out_host[3] != SIGNAL_TIMEOUT_INFO) break;
     if (int r = poll_timeout(h, attempt)) return r;
   }
@@ -1261,7 +1307,8 @@ static int enqueue_gradient(mi_gp_handle* h, bool prof) {
   HCK(launch_trmv_upper(h->buf.Z_dev, ld, h->buf.K_dev + (long)h->np * ld, h->n, h->alpha_dev, h->stream, h->btp), "trmv");
   // the final reduction writes the gradient straight into the handle's pinned host buffer (device-visible)
   HCK(launch_grad_contract(h->spec, h->theta_dev, h->buf.X_dev, h->n, h->buf.W_dev, ld, h->alpha_dev, h->part_dev,
-                           h->grad_host, h->stream, h->btp), "grad_contract");
+                           h->grad_host, h->stream, h->btp, h->lr_sync_dev + (h->btp ? h->btp->nb : 1), h->out_host + 5, h->eval_seq),
+      "grad_contract");
   if (prof) (void)hipEventRecord(h->ev[7], h->stream);
   return 0;
 }
@@ -1353,10 +1400,11 @@ extern "C" int mi_gp_set_batch(mi_gp_handle* h, const mi_gp_batch_buffers* b) {
     HCK(hipMalloc(&h->b_part_dev, sizeof(double) * k * (size_t)grad_contract_blocks(h->n) * h->ntheta), "batch scratch");
     HCK(hipMalloc(&h->b_info_dev, sizeof(int) * 4 * k), "batch scratch");
     HCK(hipMalloc(&h->b_lr_part_dev, sizeof(double) * 2 * LML_REDUCE_BLOCKS * k), "batch scratch");
-    HCK(hipMalloc(&h->b_lr_sync_dev, sizeof(unsigned) * k), "batch scratch");
-    HCK(hipMemset(h->b_lr_sync_dev, 0, sizeof(unsigned) * k), "batch scratch");
+    HCK(hipMalloc(&h->b_lr_sync_dev, sizeof(unsigned) * 2 * k), "batch scratch");  // [0, k) lml_reduce's tickets, [k, 2k) grad_final's
+    HCK(hipMemset(h->b_lr_sync_dev, 0, sizeof(unsigned) * 2 * k), "batch scratch");
     HCK(hipHostMalloc(&h->b_grad_host, sizeof(double) * k * h->ntheta), "batch scratch");
     HCK(hipHostMalloc(&h->b_out_host, sizeof(double) * 16 * k), "batch scratch");
+    memset(h->b_out_host, 0, sizeof(double) * 16 * k);
     HCK(hipHostMalloc(&h->b_theta_host, sizeof(double) * k * h->ntheta), "batch scratch");
     h->batch_cap = b->count;
   }
@@ -1398,7 +1446,7 @@ static int batch_internal(mi_gp_handle* h, int k, const double* thetas, int what
   for (int attempt = 0;; ++attempt) {
     r = run_evaluation(h, what);
     if (r == 0) {
-      const hipError_t e = hipStreamSynchronize(h->stream);
+      const hipError_t e = wait_evaluation(h, what, k, false);
       if (e != hipSuccess) r = hfail(h, e, "stream sync");
     }
     if (r != 0) break;

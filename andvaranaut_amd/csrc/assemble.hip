@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void lml_reduce_kernel(const double* __restric
                                                          const double* __restrict__ beta, int n,
                                                          double* __restrict__ out, const int* __restrict__ info, long sK,
                                                          int sout, int sinfo, double* __restrict__ part,
-                                                         unsigned* __restrict__ sync) {
+                                                         unsigned* __restrict__ sync, double seq) {
   L += (long)blockIdx.z * sK;  // batched evaluation: problem blockIdx.z
   beta += (long)blockIdx.z * sK;
   out += (long)blockIdx.z * sout;
@@ -340,6 +340,9 @@ __global__ __launch_bounds__(256) void lml_reduce_kernel(const double* __restric
     out[0] = -0.5 * (double)n * 1.8378770664093453 - 0.5 * t2 - t1;
     if (info) out[3] = (double)info[0];  // the bad-pivot word rides in the same download as the scalars
     *sync = 0u;                          // ready for the next evaluation
+    // the evaluation's sequence number, LAST and released at system scope: a host that spins on it (pinned, coherent memory)
+    // sees the scalars above once it sees the number -- without the round trip of a stream synchronisation
+    if (seq != 0.0) __hip_atomic_store(out + 4, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -390,9 +393,9 @@ hipError_t launch_set_yrows(double* K, long ldk, int row0, int cols_pad, const d
 }
 
 hipError_t launch_lml_reduce(const double* L, long ld, const double* beta, int n, double* out, hipStream_t stream,
-                             const int* info, const Batch* bt, double* part, unsigned* sync) {
+                             const int* info, const Batch* bt, double* part, unsigned* sync, double seq) {
   lml_reduce_kernel<<<dim3((part && sync) ? LR_BLOCKS : 1, 1, bt ? bt->nb : 1), 256, 0, stream>>>(L, ld, beta, n, out, info, bt ? bt->sK : 0,
-                                                                             bt ? bt->sout : 0, bt ? bt->sinfo : 0, part, sync);
+                                                                             bt ? bt->sout : 0, bt ? bt->sinfo : 0, part, sync, seq);
   return hipGetLastError();
 }
 

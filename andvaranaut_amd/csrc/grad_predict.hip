@@ -566,7 +566,7 @@ __global__ __launch_bounds__(256) void grad_x_kernel(KernSpec spec, const double
 // grad[p] = sum_b part[b][p] in a fixed order (the weights already are 1 below the diagonal and 1/2
 // on it, which is 1/2 sum over the full symmetric matrix).
 __global__ void grad_final_kernel(const double* __restrict__ part, int nblk, int P, double* __restrict__ grad, long spart,
-                                  int sgrad) {
+                                  int sgrad, unsigned* __restrict__ done, double* __restrict__ flag, int sflag, double seq) {
   part += (long)blockIdx.z * spart;  // batched evaluation: problem blockIdx.z
   grad += (long)blockIdx.z * sgrad;
   const int p = blockIdx.x;
@@ -579,7 +579,19 @@ __global__ void grad_final_kernel(const double* __restrict__ part, int nblk, int
     if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
     __syncthreads();
   }
-  if (threadIdx.x == 0) grad[p] = red[0];
+  if (threadIdx.x == 0) {
+    grad[p] = red[0];
+    if (done && seq != 0.0) {
+      // LAST kernel of an LML + gradient evaluation: the workgroup that completes the gradient publishes the evaluation's
+      // sequence number, released at system scope (the host may spin on it instead of synchronising the stream)
+      __threadfence_system();
+      done += blockIdx.z;
+      if (atomicAdd(done, 1u) == (unsigned)P - 1u) {
+        *done = 0u;  // ready for the next evaluation
+        __hip_atomic_store(flag + (long)blockIdx.z * sflag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
 }
 
 // mean[i] = A_i . beta ; var[i] = kdiag - |A_i|^2 (+ noise), one wave per prediction point
@@ -631,7 +643,8 @@ static bool has_ratquad(const KernSpec& spec) {
 }
 
 hipError_t launch_grad_contract(const KernSpec& spec, const double* theta, const double* X, int n, const double* W,
-                                long ldw, const double* alpha, double* part, double* grad, hipStream_t stream, const Batch* bt) {
+                                long ldw, const double* alpha, double* part, double* grad, hipStream_t stream, const Batch* bt,
+                                unsigned* done, double* flag, double seq) {
   const int nblk = grad_contract_blocks(n);
   const int P = spec.nkern * spec.d + 2 * spec.nkern + 2;
   const dim3 grid(nblk, 1, bt ? bt->nb : 1);
@@ -662,7 +675,7 @@ hipError_t launch_grad_contract(const KernSpec& spec, const double* theta, const
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  grad_final_kernel<<<dim3(P, 1, bt ? bt->nb : 1), 256, 0, stream>>>(part, nblk, P, grad, sp, sth);
+  grad_final_kernel<<<dim3(P, 1, bt ? bt->nb : 1), 256, 0, stream>>>(part, nblk, P, grad, sp, sth, done, flag, bt ? bt->sout : 0, seq);
   return hipGetLastError();
 }
 
@@ -707,7 +720,7 @@ hipError_t launch_grad_contract_slab(const KernSpec& spec, const double* theta, 
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  grad_final_kernel<<<P, 256, 0, stream>>>(part, nblk, P, grad, 0, 0);
+  grad_final_kernel<<<P, 256, 0, stream>>>(part, nblk, P, grad, 0, 0, nullptr, nullptr, 0, 0.0);
   return hipGetLastError();
 }
 

@@ -153,7 +153,7 @@ hipError_t launch_set_yrows(double* K, long ldk, int row0, int cols_pad, const d
 constexpr int LML_REDUCE_BLOCKS = 16;
 hipError_t launch_lml_reduce(const double* L, long ld, const double* beta, int n, double* out, hipStream_t stream,
                              const int* info = nullptr, const Batch* bt = nullptr, double* part = nullptr,
-                             unsigned* sync = nullptr);
+                             unsigned* sync = nullptr, double seq = 0.0);
 
 // ---------------------------------------------------------------- grad_predict.hip
 hipError_t launch_set_identity_blocks(double* U, long ld, int nblocks, hipStream_t stream, const Batch* bt = nullptr);
@@ -166,7 +166,9 @@ int grad_contract_blocks(int n);
 // part: [grad_contract_blocks(n)][ntheta] scratch; grad: [ntheta] (natural parameters, C-ABI order)
 hipError_t launch_grad_contract(const KernSpec& spec, const double* theta, const double* X, int n, const double* W,
                                 long ldw, const double* alpha, double* part, double* grad, hipStream_t stream,
-                                const Batch* bt = nullptr);
+                                const Batch* bt = nullptr, unsigned* done = nullptr, double* flag = nullptr, double seq = 0.0);
+// done / flag / seq (and launch_lml_reduce's seq): the evaluation's LAST kernel publishes its sequence number in pinned host
+// memory -- lml_reduce in out[4], the gradient's final reduction in flag[0] (per problem of a batch: + sout) -- see wait_evaluation()
 // column slab [col0, col0+cols) of the lower triangle (distributed K^-1): W points at element (row0, col0), row0 <= col0
 int grad_contract_slab_blocks(int n, int col0, int cols);
 hipError_t launch_grad_contract_slab(const KernSpec& spec, const double* theta, const double* X, int n, const double* W,

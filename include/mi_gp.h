@@ -198,7 +198,16 @@ MI_GP_API int mi_gp_predict_grad(mi_gp_handle* h, const double* Xnew_dev, int m,
  *   45 two-stream evaluations queue their first two kernels (theta / y rows, assembly) on the PANEL stream, so that the first
  *      leaf follows them in stream order instead of behind a cross-stream edge (default 1; N = 1024 -7 %, 2048 -4 %, from 32 tile
  *      columns on 0.1-0.4 %); scheduling only
- * 8, 14, 16, 18, 19, 21, 26, 27, 30, 31, 38 and 45 only change scheduling (bit-identical results); 20 moves tiles between the
+ *   47 the HOST's wait at the end of an evaluation: its last kernel publishes the evaluation's sequence number in the pinned result
+ *      buffer, behind the values it stands for, and the call spins on that word for up to this many microseconds (default 2000;
+ *      0: never) before it falls back to hipStreamSynchronize -- a stream synchronisation costs 6-8 us behind the kernel's end
+ *      (N = 128 LML + gradient 0.101 -> 0.090 ms, 1024 0.310 -> 0.291, 4096 1.424 -> 1.387).  An evaluation that outlasts the budget
+ *      makes the handle's next 15 calls skip the spin (a long evaluation costs a core 2 ms in 16 calls); every 256th call
+ *      synchronises the stream all the same.  The word is the LAST thing the evaluation's last kernel does: when a call returns
+ *      through the spin every device-side read and write of the evaluation is complete (that kernel writes nothing but the
+ *      pinned result buffer) and only its retirement may be outstanding -- the handle's buffers may be read or overwritten
+ *      from any stream, as after a synchronisation.  Same bits.
+ * 8, 14, 16, 18, 19, 21, 26, 27, 30, 31, 38, 45 and 47 only change scheduling (bit-identical results); 20 moves tiles between the
  * two GEMM kernels (same k order); 2, 4-7, 9, 32, 35, 37 and 46 regroup sums (agreement to rounding), and so does 0 where it changes
  * the super-panel width (20 to 60 tile columns).
  * Unknown ids return -1.  (Round 1's options 1, 3, 10-13 -- GEMM variants, hipGraph replay, persistent bulk kernels,

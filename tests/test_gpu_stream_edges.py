@@ -271,3 +271,39 @@ def test_tile_column_counts_around_the_round5_thresholds(ntc, ragged):
     th = np.stack([orc.synth_theta(d, kv=1.0 + 0.3 * i) for i in range(3)])
     assert np.array_equal(gp.lml_batch(th), np.array([gp.lml(t) for t in th]))
     gp.close()
+
+
+@pytest.mark.parametrize("N,d", [(200, 3), (1500, 4), (3000, 6)])
+def test_spin_wait_on_the_sequence_word_returns_what_a_stream_synchronisation_returns(N, d):
+    """Round 6, option 47: the host spins on the sequence number the evaluation's last kernel publishes in the pinned result
+    buffer (behind the scalars / the gradient, released at system scope) instead of synchronising the stream.  Same values,
+    bit for bit, with the spin off (0), on (default 2000 us) and with a budget every evaluation runs into (1 us: the call
+    falls back to the stream synchronisation and the next 15 calls do not spin) -- LML, LML + gradient, batches, the
+    conditional factor behind predict; thetas alternate so that a stale buffer would show."""
+    MiGP, orc = _mods()
+    X, y = orc.synth_problem(N, d, seed=N)
+    ths = [orc.synth_theta(d, kv=1.0 + 0.1 * i) for i in range(6)]
+    Xs = X[:16] + 0.01
+    gp = MiGP(X, y, "Matern52")
+    assert gp.get_option(47, -1) == 2000
+    ref = None
+    for budget in (0, 2000, 1, 2000):
+        gp.set_option(47, budget)
+        got = []
+        for rep in range(3):
+            for t in ths:
+                v = gp.lml(t)
+                v2, g = gp.lml_grad(t)
+                assert v2 == v
+                got.append((v, g.tobytes()))
+        vb, gb = gp.lml_grad_batch(np.stack(ths))
+        got.append((vb.tobytes(), gb.tobytes()))
+        got.append(gp.lml_batch(np.stack(ths[::-1])).tobytes())
+        m, var = gp.predict(ths[2], Xs)
+        got.append((m.tobytes(), var.tobytes()))
+        if ref is None:
+            ref = got
+            o = orc.lml(X, y, ["Matern52"], [], ths[0])
+            assert abs(got[0][0] - o) <= 1e-10 * abs(o)
+        assert got == ref, budget
+    gp.close()

@@ -165,3 +165,34 @@ def test_predict_through_the_inverse_factor_matches_oracle(N, d, kernel, M):
     mu_d, _ = gp.predict(theta, Xn)
     assert np.allclose(mu_d, mu_o, rtol=1e-8, atol=1e-9)
     gp.close()
+
+
+def test_pinned_host_route_of_small_predict_calls_returns_the_device_routes_bits(monkeypatch):
+    """Round 6: up to MiGP.PINNED_IO_MAX_POINTS points travel through pinned host memory the kernels address directly (no
+    torch copies or synchronisations around the call).  Same kernels on the same values: the blocked solve, the route through
+    U = L^-T and predict_grad return the device-buffer route's bits -- 1 point, the limit, one more than the limit."""
+    MiGP, orc = _mods()
+    N, d = 1500, 5
+    X, y = orc.synth_problem(N, d, seed=3)
+    theta = orc.synth_theta(d)
+    gp = MiGP(X, y, "Matern52")
+    lim = MiGP.PINNED_IO_MAX_POINTS
+    assert lim >= 16
+    Xs = np.random.default_rng(0).random((lim + 1, d))
+    got = {}
+    for route in ("pinned", "device"):
+        if route == "device":
+            monkeypatch.setattr(MiGP, "PINNED_IO_MAX_POINTS", 0)
+        for m in (1, 7, lim, lim + 1):
+            got[route, m, "solve"] = gp.predict(theta, Xs[:m], via_inverse=False)
+            got[route, m, "u"] = gp.predict(theta, Xs[:m], via_inverse=True)
+        for m in (1, 7):
+            got[route, m, "grad"] = gp.predict_grad(theta, Xs[:m], refactor=False)
+    for (route, m, what), v in got.items():
+        if route == "pinned":
+            w = got["device", m, what]
+            assert all(np.array_equal(a, b) for a, b in zip(v, w)), (m, what)
+    rmu, rvar = orc.predict(X, y, Xs[:7], ["Matern52"], [], theta)
+    assert np.allclose(got["pinned", 7, "solve"][0], rmu, rtol=1e-9, atol=1e-9)
+    assert np.allclose(got["pinned", 7, "solve"][1], rvar, rtol=1e-8, atol=1e-11)
+    gp.close()

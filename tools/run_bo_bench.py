@@ -4,7 +4,9 @@ import sys, os, time
 import numpy as np
 import scipy.stats as st
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-from andvaranaut_amd import GPMCMC, uniform
+from andvaranaut_amd import GPMCMC, MiGP, uniform
+if len(sys.argv) > 2 and sys.argv[2] == "device":  # A/B: small predict calls through device buffers (round 5's route)
+    MiGP.PINNED_IO_MAX_POINTS = 0
 d, n0 = 6, int(sys.argv[1]) if len(sys.argv) > 1 else 4000
 priors = [st.uniform(loc=0, scale=1) for _ in range(d)]
 fun = lambda x: np.array([np.sum((x - 0.3) ** 2) + 0.3 * np.sin(6 * np.sum(x))])

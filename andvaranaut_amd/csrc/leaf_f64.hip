@@ -901,16 +901,13 @@ __device__ __forceinline__ void poll_signal(const unsigned* ptr, unsigned val, i
   long spins = 0;
   const long limit = 1L << limit_log2;
   if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == SIGNAL_TIMEOUT_INFO) return;
-  // (relaxed loads in the loop and ONE acquire behind it: an acquire load at system scope is a load plus a cache invalidation,
-  // and the polls at a super-panel boundary last 100-200 us beside a bulk update)
-  while (__hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < val) {
+  while (__hip_atomic_load(ptr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < val) {
     __builtin_amdgcn_s_sleep(4);
     if (++spins > limit) {
       atomicMin(info, SIGNAL_TIMEOUT_INFO);
       break;
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
 }
 
 __global__ __launch_bounds__(512, 1) void potrf_leaf128_kernel(double* __restrict__ Ablk, long lda,

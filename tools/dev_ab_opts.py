@@ -13,7 +13,7 @@ sets = args[3:]
 X, y = synth_problem(N, d, seed=0)
 gp = MiGP(X, y, kern, need_grad=grad)
 th = theta_sequence(d, max(8, 8 * batch), seed=0)
-DEFAULTS = {0: 1, 2: 0, 4: 1 << 20, 5: 0, 6: 0, 7: 1024, 8: 1 << 20, 9: 1, 14: 8, 16: 1, 18: 1536, 19: 1024, 20: 72, 21: 8, 26: 2, 32: 2048, 35: 32, 37: 24, 38: 8, 45: 1, 46: 31, 47: 2000}
+DEFAULTS = {0: 1, 2: 0, 4: 1 << 20, 5: 0, 6: 0, 7: 1024, 8: 1 << 20, 9: 1, 14: 8, 16: 1, 18: 1536, 19: 1024, 20: 72, 21: 8, 26: 2, 30: 16, 31: 48, 32: 2048, 35: 32, 37: 24, 38: 8, 45: 1, 46: 31, 47: 2000}
 res = {s: [] for s in sets}
 vals = {}
 enq = {}

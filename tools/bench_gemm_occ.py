@@ -4,6 +4,8 @@ import ctypes, json, os, sys
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from andvaranaut_amd import _lib
+if os.environ.get("MIGP_LIB"):
+    _lib.LIB_PATH = os.path.abspath(os.environ["MIGP_LIB"])
 lib = _lib.load()
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 dev = torch.device("cuda:0")
@@ -12,9 +14,14 @@ ld = 16384 + 16
 A = torch.randn(16384 + 128, ld, dtype=torch.float64, device=dev) * 0.01
 # (m, n, k): the bulk updates of an N = 8192 evaluation (48 / 40 / 32 trailing tile columns), an (a2) update, N = 16384's 1536-tile part
 shapes = [(6272, 6144, 1024), (5248, 5120, 1024), (4224, 4096, 1024), (7168, 896, 1024), (3200, 3072, 1024), (3200, 3072, 512)]
+if os.environ.get("ONLY"):  # ONLY="5248,5120,1024,64x64,0": one shape, one kernel, one occupancy (counter passes)
+    o = os.environ["ONLY"].split(",")
+    shapes = [(int(o[0]), int(o[1]), int(o[2]))]
 for (m, n, k) in shapes:
     for small_below, name in ((1 << 20, "64x64"), (0, "128x128")):
         for opc in (0, 1):
+            if os.environ.get("ONLY") and (name != o[3] or opc != int(o[4])):
+                continue
             P, C = A[:m, 8192:8192 + k], A[:m, 0:n]
             def run():
                 r = lib.mi_gp_gemm_f64_tuned(0, 1, m, n, k, -1.0, P.data_ptr(), ld, P.data_ptr(), ld, 1.0, C.data_ptr(), ld, 1, 0,

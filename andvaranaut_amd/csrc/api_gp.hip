@@ -490,6 +490,7 @@ static hipError_t syrk_trapezoid(mi_gp_handle* h, double* A, long lda, int ntr, 
   p.alpha = -1.0;
   p.beta = 1.0;
   p.kflush = kflush;
+  p.dead_last_half = 1;  // (every trapezoid of the factorisation ends in the y^T tile row)
   // algorithmic flops (nb*m^2 for the lower-triangle SYRK, 2*nb*rows*cols for the block
   // below it, one y^T row for the folded-in forward solve); the MFMA work issued is slightly larger
   // (full diagonal tiles, a 128-row tile for the y row).

@@ -502,8 +502,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel_s(GemmParams p) {
       ti = 2 * pti + (quad >> 1);
       tj = 2 * ptj + (quad & 1);
       if (p.tri && tj > ti) return;  // the quadrant above the diagonal of a diagonal parent tile
+      if (p.dead_last_half && ti == 2 * p.sub_mt - 1) return;  // the all-zero half of the y^T tile row
     } else {
       tile_from_index(p, bid, ti, tj);
+      if (p.dead_last_half && ti == p.mt - 1) return;
     }
     if (p.kmode == 2) ti = p.mt - 1 - ti;
     if (p.kmode == 4 && !p.tri) { tj = p.nt - 1 - (int)blockIdx.x / p.mt; ti = (int)blockIdx.x % p.mt; }  // longest-k columns first (LPT order)

@@ -63,6 +63,10 @@ struct GemmParams {
   // set by the launcher for that second launch: 64x64 tile 4 e + quadrant belongs to 128x128 tile sub_base + e of the
   // parent enumeration (sub_mt x sub_nt tiles of 128); -1: off
   int sub_base = -1, sub_mt = 0, sub_nt = 0;
+  // The factorisation's trapezoids end in the y^T tile row: rows np .. np + 127 hold y^T in row np and zeros below, so the LOWER
+  // 64-row half of that tile row is all zeros before and after every update.  1: the 64x64-tile kernel's workgroups of that half
+  // return at once (2-8 % of the workgroups of an update at N = 2048 .. 8192; the 128x128-tile kernel computes whole tiles)
+  int dead_last_half = 0;
   // Panel-list mode (pl != nullptr; sharded driver, api_shard.hip): ONE launch updates the lower trapezoids of pl_n column
   // panels of a block-cyclically distributed matrix, C_e -= P[rows >= g_e] P[rows of panel e]^T for e = pl_first ...
   // pl[e] = {cum, g, ccol, w}: 128x128 tiles of the panels before e, global tile row of panel e's diagonal block, tile

@@ -1,5 +1,6 @@
 """Alone-on-the-chip rate of bulk-update shapes on both GEMM kernels at one and at two workgroups per CU, through
-mi_gp_gemm_f64_tuned with HIP events:  python tools/bench_gemm_occ.py [reps]"""
+mi_gp_gemm_f64_tuned with HIP events:  python tools/bench_gemm_occ.py [reps]
+(MIGP_LIB=<libmi_gp.so>: another build; ONLY="m,n,k,64x64|128x128,0|1": one shape, kernel and occupancy -- for counter passes)"""
 import ctypes, json, os, sys
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))

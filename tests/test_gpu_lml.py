@@ -279,6 +279,30 @@ def test_tuning_options_do_not_change_results():
     gp.close()
 
 
+@pytest.mark.parametrize("N", [1000, 3000, 5200])
+def test_rows_below_the_y_row_stay_zero(N):
+    """K_dev's last tile row carries y^T in row Np and zeros below; every trapezoid update of the
+    factorisation includes it.  The 64x64-tile kernel skips the lower, all-zero half of that tile row (round 6,
+    GemmParams::dead_last_half): those rows must be exactly zero after an evaluation, the row of beta = L^-1 y finite, and
+    the LML the oracle's (gpmcmc.py:313-318)."""
+    import torch
+    MiGP, orc = _mods()
+    d = 5
+    X, y = orc.synth_problem(N, d, seed=N)
+    theta = orc.synth_theta(d)
+    gp = MiGP(X, y, "RBF", need_grad=False)
+    v = gp.lml(theta)
+    ref = orc.lml(X, y, ["RBF"], [], theta)
+    assert abs(v - ref) <= 1e-10 * abs(ref)
+    npad = gp.np_
+    torch.cuda.synchronize()
+    below = gp.K_t[npad + 1:npad + 128, :npad]
+    assert int(torch.count_nonzero(below).item()) == 0
+    beta = gp.K_t[npad, :N]
+    assert bool(torch.isfinite(beta).all().item()) and float(beta.abs().max().item()) > 0.0
+    gp.close()
+
+
 def test_shared_lane_schedule_is_bit_identical_to_the_default():
     """GPMCMC.fit runs chains that share a GPU on single-stream handles between 20 and 64 tile columns, with the
     super-panel width the two-stream default would pick pinned (options 2 = 4, 0 = 0): same arithmetic, same bits --
